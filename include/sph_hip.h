@@ -1,0 +1,187 @@
+/* sph_hip.h — C ABI of the MI355X (gfx950) SPH step.
+ *
+ * This is the drop-in boundary for the hot path of
+ * DanielaCourel/smoothed_particle_hydrodynamics: everything SPH::step()
+ * (reference src/sph.cpp:190-304) does between "particles in" and "particles out".
+ * The reference has no FFI layer; its seam is the C++ class `SPH` (reference
+ * src/sph.h:15-216).  Each entry point below names the member(s) of that class it
+ * replaces, so a maintainer can keep sph.h unchanged and forward the bodies in sph.cpp
+ * to this library.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary;
+ *   - every call returns SPH_HIP_OK (0) or a negative sph_hip_status; the message for the
+ *     last failure on a context is available from sph_hip_last_error();
+ *   - host arrays use the reference's layouts: positions / velocities / accelerations
+ *     interleaved xyz (`mPosition[3*i+c]`, reference src/particle.h:13-18), one float or
+ *     int per particle otherwise, all indexed by the particle's persistent index;
+ *   - device memory, streams and events are owned by the context.
+ */
+#ifndef SPH_HIP_H
+#define SPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_HIP_ABI_VERSION 1
+
+typedef enum sph_hip_status {
+   SPH_HIP_OK = 0,
+   SPH_HIP_ERR_INVALID = -1,   /* bad argument / bad state */
+   SPH_HIP_ERR_DEVICE = -2,    /* a HIP runtime call failed */
+   SPH_HIP_ERR_CAPACITY = -3,  /* more particles than the context was created for */
+   SPH_HIP_ERR_NO_DEVICE = -4  /* no usable gfx950 device */
+} sph_hip_status;
+
+/* Neighbour semantics of a context.
+ *   REF  — the shipped search: octant of 2h-voxels, LCG-sampled chunks of 8 of which 4 are
+ *          tested, at most 28 stored neighbours (reference src/sph.cpp:484-692), then the
+ *          list-driven sums.  Integer outputs are identical to the reference's.
+ *   FULL — every neighbour inside the interaction radius, found on a grid of cell edge
+ *          >= h (27 cells), visited in ascending (cell id, particle index); per-pair
+ *          arithmetic is the reference's (src/sph.cpp:737-761, 825-884). */
+typedef enum sph_hip_mode { SPH_HIP_MODE_REF = 0, SPH_HIP_MODE_FULL = 1 } sph_hip_mode;
+
+/* The constants the hot path reads — the protected members SPH::SPH() initialises
+ * (reference src/sph.h:149-210, src/sph.cpp:46-98).  Field order is ABI. */
+typedef struct sph_hip_params {
+   int32_t cells_x, cells_y, cells_z; /* mGridCellsX/Y/Z   (voxel grid, edge 2h)        */
+   float cell_size;                   /* mCellSize                                      */
+   float max_x, max_y, max_z;         /* mMaxX/Y/Z                                      */
+   float h;                           /* mH                                             */
+   float h2;                          /* mH2                                            */
+   float hscaled;                     /* mHScaled                                       */
+   float hscaled2;                    /* mHScaled2                                      */
+   float hscaled6;                    /* mHScaled6                                      */
+   float hscaled9;                    /* mHScaled9                                      */
+   float htimes2;                     /* mHTimes2                                       */
+   float htimes2inv;                  /* mHTimes2Inv                                    */
+   float sim_scale;                   /* mSimulationScale                               */
+   float sim_scale_inv;               /* mSimulationScaleInverse                        */
+   float kernel1, kernel2, kernel3;   /* mKernel1Scaled, mKernel2Scaled, mKernel3Scaled */
+   float rho0;                        /* mRho0                                          */
+   float stiffness;                   /* mStiffness        (SPH::setStiffness)          */
+   float viscosity;                   /* mViscosityScalar  (SPH::setViscosityScalar)    */
+   float time_step;                   /* mTimeStep         (SPH::setTimeStep)           */
+   float damping;                     /* mDamping          (SPH::setDamping)            */
+   float cfl_limit, cfl_limit2;       /* mCflLimit, mCflLimit2 (SPH::setCflLimit)       */
+   float gravity[3];                  /* mGravity          (SPH::setGravity)            */
+   float grav_const;                  /* mGravConstant                                  */
+   float central_mass;                /* mCentralMass                                   */
+   float central_pos[3];              /* mCentralPos                                    */
+   float softening;                   /* mSoftening                                     */
+   int32_t examine_count;             /* mExamineCount (32)                             */
+   /* FULL-mode grid (no reference counterpart): cell edge >= h */
+   int32_t full_cells_x, full_cells_y, full_cells_z;
+   float full_cell_inv;
+} sph_hip_params;
+
+typedef struct sph_hip_context sph_hip_context;
+
+/* ---- construction -------------------------------------------------------------------- */
+
+/* Constants for smoothing length h and a voxel grid of the given shape, derived exactly as
+ * SPH::SPH() derives them (reference src/sph.cpp:46-98: double pow() narrowed to float,
+ * float kernel normalisations).  h = 0.1f, cells = 32^3 gives the reference's defaults. */
+int sph_hip_params_default(sph_hip_params* out, float h, int cells_x, int cells_y, int cells_z);
+
+/* Replaces the allocations in SPH::SPH() (reference src/sph.cpp:100-113): device storage for
+ * up to `capacity` particles on HIP device `device`. */
+int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
+                   int device);
+void sph_hip_destroy(sph_hip_context* ctx);
+
+/* Last error text for ctx (or for the failed create when ctx is NULL). Never NULL. */
+const char* sph_hip_last_error(const sph_hip_context* ctx);
+
+/* Replaces the six GUI setters + the constructor constants (reference src/sph.cpp:1219-1289).
+ * Takes effect at the start of the next phase call; grid shape and h may not change. */
+int sph_hip_set_params(sph_hip_context* ctx, const sph_hip_params* params);
+int sph_hip_get_params(const sph_hip_context* ctx, sph_hip_params* out);
+
+/* ---- particle state ------------------------------------------------------------------- */
+
+/* Host -> device.  Replaces the fill of Particle::mPosition/mVelocity/mMass done by
+ * initParticlePolitionsSphere() and the constructor (reference src/sph.cpp:105-108,
+ * 361-425).  pos/vel: 3*n floats interleaved; mass: n floats.  Sets the live count. */
+int sph_hip_upload(sph_hip_context* ctx, int n, const float* pos, const float* vel,
+                   const float* mass);
+
+/* Device -> host mirror of `Particle` (reference src/particle.h:13-18), any pointer may be
+ * NULL: mPosition, mVelocity, mDensity, mAcceleration, mNeighborCount, indexed by the
+ * particle's persistent index.  This is what SPH::getParticles() consumers read
+ * (reference src/visualization.cpp:144-158). */
+int sph_hip_download(sph_hip_context* ctx, float* pos, float* vel, float* density, float* acc,
+                     int32_t* neighbor_count);
+
+int sph_hip_particle_count(const sph_hip_context* ctx);
+
+/* ---- the step -------------------------------------------------------------------------- */
+
+/* SPH::step() (reference src/sph.cpp:190-304): the five phases below, in order. */
+int sph_hip_step(sph_hip_context* ctx);
+/* `steps` back-to-back steps with no host synchronisation in between. */
+int sph_hip_run(sph_hip_context* ctx, int steps);
+
+/* SPH::voxelizeParticles() + clearGrid() (reference src/sph.cpp:429-481): cell ids, per-cell
+ * counts, cell-sorted order (ascending particle index inside a cell). */
+int sph_hip_voxelize(sph_hip_context* ctx);
+/* The findNeighbors() loop (reference src/sph.cpp:216-231, 484-692).  REF: builds
+ * mNeighbors / mNeighborDistancesScaled / mNeighborCount.  FULL: no stored lists — the
+ * neighbour walk is fused into the two sums; this call is a no-op kept for phase timing. */
+int sph_hip_find_neighbors(sph_hip_context* ctx);
+/* The computeDensity() loop (reference src/sph.cpp:242-249, 721-766). */
+int sph_hip_compute_density(sph_hip_context* ctx);
+/* The computeAcceleration() loop (reference src/sph.cpp:270-277, 778-934). */
+int sph_hip_compute_acceleration(sph_hip_context* ctx);
+/* The integrate() loop (reference src/sph.cpp:285-289, 937-1022) incl. KE/PE totals. */
+int sph_hip_integrate(sph_hip_context* ctx);
+
+/* Wait for all queued work of ctx. */
+int sph_hip_synchronize(sph_hip_context* ctx);
+
+/* ---- diagnostics ------------------------------------------------------------------------ */
+
+/* Milliseconds (fractional, unlike the reference's truncated ints) spent in the six phases of
+ * the last sph_hip_step(): voxelize, findNeighbors, density, pressure(=0), acceleration,
+ * integrate — the arguments of SPH::updateElapsed (reference src/sph.cpp:292-299). */
+int sph_hip_get_timings(sph_hip_context* ctx, float ms[6]);
+/* Sums of the same six phase times over the sph_hip_step() calls since the last
+ * sph_hip_reset_timings() (at most the most recent 128 steps are kept); *steps = how many
+ * steps the sums cover.  Measured with HIP events on the context's own stream. */
+int sph_hip_get_phase_totals(sph_hip_context* ctx, double ms[6], int32_t* steps);
+int sph_hip_reset_timings(sph_hip_context* ctx);
+
+/* mKineticEnergyTotal / mPotentialEnergyTotal of the last integrate
+ * (reference src/sph.cpp:1001-1013).  Summed in double in a fixed tree order; the
+ * reference's serial fp32 sum is order-dependent, so compare with a tolerance. */
+int sph_hip_get_energy(sph_hip_context* ctx, float* kinetic, float* potential);
+
+/* The three numbers the reference appends to out/neighbors.txt each step
+ * (reference src/sph.cpp:204-232): sum/N (integer division), max, min(<=34). */
+int sph_hip_get_neighbor_stats(sph_hip_context* ctx, int32_t* avg, int32_t* max, int32_t* min);
+
+/* mVoxelCoords / mVoxelIds (reference src/sph.cpp:466-472); coords: 3*n ints. */
+int sph_hip_download_voxels(sph_hip_context* ctx, int32_t* coords_xyz, int32_t* ids);
+/* Per-voxel occupancy, what callers get from SPH::getGrid()[i].count()
+ * (reference src/visualization.cpp:178-193). `counts` has cells_x*cells_y*cells_z entries
+ * (REF) or full_cells_x*full_cells_y*full_cells_z (FULL). */
+int sph_hip_download_grid_counts(sph_hip_context* ctx, int32_t* counts);
+/* REF mode only: mNeighbors / mNeighborDistancesScaled, n*examine_count entries each
+ * (reference src/sph.cpp:112-113). */
+int sph_hip_download_neighbor_lists(sph_hip_context* ctx, uint32_t* neighbors, float* distances);
+
+/* ---- streams ----------------------------------------------------------------------------- */
+
+/* Opaque device handles for callers that overlap communication with compute: the HIP
+ * stream all of ctx's kernels run on. */
+void* sph_hip_stream(sph_hip_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPH_HIP_H */

@@ -1,0 +1,50 @@
+"""Builds csrc/ into smoothed_particle_hydrodynamics_amd/libsph_hip.so with hipcc for gfx950.
+
+The library is built IN-TREE so that it travels with a snapshot of the repository; it is
+git-ignored.  hipcc cross-compiles without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["sph_hip.hip"]
+HEADERS = ["sph_device.h", "cell_build.h", "pair_math.h", "full_kernels.h", "ref_kernels.h",
+           "common_kernels.h", os.path.join("..", "..", "include", "sph_hip.h")]
+
+# -ffp-contract=off: the reference's x86-64 IEEE build has no FMA contraction; neighbour
+# membership (d^2 < h^2) and the order-sensitive viscous sum must round identically.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-shared", "-Wall"]
+
+
+def library_path():
+    return os.path.join(HERE, "libsph_hip.so")
+
+
+def _stale(out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP library if missing or older than its sources. Returns its path."""
+    out = library_path()
+    if not force and not _stale(out):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libsph_hip.so")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,225 @@
+// Uniform-grid cell build for gfx950: cell hash + counting sort + in-cell ordering.
+//
+// Replaces SPH::clearGrid() / SPH::voxelizeParticles() (reference src/sph.cpp:429-481).  The
+// reference appends particle indices to one QList per voxel in a serial loop, so every voxel
+// list is in ascending particle index.  Here:
+//   1. k_hash_count   cell id per particle, arrival slot from one counting atomic per cell run
+//   2. k_scan_*       exclusive scan of the per-cell counts (wave64 shuffles + LDS carries)
+//   3. k_scatter      cell-sorted permutation (arbitrary order inside a cell)
+//   4. k_rank_*       order inside each cell fixed to ascending particle index — the same
+//                     lists the reference builds, independent of atomic arrival order
+#pragma once
+
+#include "sph_device.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 16
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+// ---- 1. hash + count ------------------------------------------------------------------
+// Lanes of a wave that hold consecutive particles of the same cell (the common case once the
+// state is cell-sorted) share ONE global atomic: the run's first lane adds the run length and
+// the others take base + their rank in the run.
+template <bool WRITE_VOX>
+__global__ void __launch_bounds__(256)
+k_hash_count(const float4* __restrict__ posm, int n, CellGrid g, uint32_t* __restrict__ key,
+             uint32_t* __restrict__ slot, uint32_t* __restrict__ cell_count,
+             int32_t* __restrict__ vox)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   const int lane = threadIdx.x & (SPH_WAVE - 1);
+   const bool live = i < n;
+   uint32_t c = 0xffffffffu;
+   if (live) {
+      const float4 p = posm[i];
+      int cx, cy, cz;
+      c = cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+      key[i] = c;
+      if (WRITE_VOX) {
+         vox[3 * i + 0] = cx;
+         vox[3 * i + 1] = cy;
+         vox[3 * i + 2] = cz;
+      }
+   }
+   // run detection across the wave
+   const uint32_t prev = __shfl_up(c, 1);
+   const bool head = (lane == 0) || (prev != c);
+   const unsigned long long heads = __ballot(head);
+   // position of my run's head = highest set bit of heads at or below my lane
+   const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+   const int head_lane = 63 - __clzll(below);
+   // run length = distance to the next head above head_lane (or wave end)
+   const unsigned long long above = (head_lane == 63) ? 0ull : (heads >> (head_lane + 1));
+   const int run_len = above ? (__ffsll((long long)above)) : (SPH_WAVE - head_lane);
+   uint32_t base = 0;
+   if (live && head) base = atomicAdd(&cell_count[c], (uint32_t)run_len);
+   base = __shfl(base, head_lane);
+   if (live) slot[i] = base + (uint32_t)(lane - head_lane);
+}
+
+// ---- 2. exclusive scan of cell counts ------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+#pragma unroll
+   for (int d = 1; d < SPH_WAVE; d <<= 1) {
+      uint32_t t = __shfl_up(v, d);
+      if (lane >= d) v += t;
+   }
+   return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, total in *total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total)
+{
+   __shared__ uint32_t wave_sums[SCAN_THREADS / SPH_WAVE];
+   const int lane = threadIdx.x & (SPH_WAVE - 1);
+   const int w = threadIdx.x / SPH_WAVE;
+   const uint32_t inc = wave_inclusive_scan(v, lane);
+   if (lane == SPH_WAVE - 1) wave_sums[w] = inc;
+   __syncthreads();
+   uint32_t carry = 0, tot = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_THREADS / SPH_WAVE; k++) {
+      const uint32_t s = wave_sums[k];
+      if (k < w) carry += s;
+      tot += s;
+   }
+   __syncthreads();
+   *total = tot;
+   return carry + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_reduce(const uint32_t* __restrict__ count, int ncells, uint32_t* __restrict__ part)
+{
+   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+   uint32_t s = 0;
+   if (base + SCAN_ITEMS <= ncells) {
+      const uint4* p = reinterpret_cast<const uint4*>(count + base);
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS / 4; k++) {
+         const uint4 v = p[k];
+         s += v.x + v.y + v.z + v.w;
+      }
+   } else {
+      for (int k = 0; k < SCAN_ITEMS; k++)
+         if (base + k < ncells) s += count[base + k];
+   }
+   uint32_t total;
+   block_exclusive_scan(s, &total);
+   if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+// one block: exclusive scan of the tile totals in place
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_parts(uint32_t* __restrict__ part, int ntiles)
+{
+   uint32_t carry = 0;
+   for (int base = 0; base < ntiles; base += SCAN_THREADS) {
+      const int idx = base + threadIdx.x;
+      const uint32_t v = idx < ntiles ? part[idx] : 0u;
+      uint32_t total;
+      const uint32_t ex = block_exclusive_scan(v, &total);
+      if (idx < ntiles) part[idx] = carry + ex;
+      carry += total;
+   }
+}
+
+// writes cell_start[0..ncells] and clears the counts for the next build
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restrict__ part,
+             uint32_t* __restrict__ cell_start)
+{
+   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+   uint32_t v[SCAN_ITEMS];
+   uint32_t s = 0;
+   if (base + SCAN_ITEMS <= ncells) {
+      const uint4* p = reinterpret_cast<const uint4*>(count + base);
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS / 4; k++) {
+         const uint4 q = p[k];
+         v[4 * k + 0] = q.x;
+         v[4 * k + 1] = q.y;
+         v[4 * k + 2] = q.z;
+         v[4 * k + 3] = q.w;
+      }
+   } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; k++) v[k] = (base + k < ncells) ? count[base + k] : 0u;
+   }
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+   uint32_t total;
+   uint32_t run = part[blockIdx.x] + block_exclusive_scan(s, &total);
+   if (base + SCAN_ITEMS <= ncells) {
+      uint4* o = reinterpret_cast<uint4*>(cell_start + base);
+      uint4* z = reinterpret_cast<uint4*>(count + base);
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS / 4; k++) {
+         uint4 q;
+         q.x = run; run += v[4 * k + 0];
+         q.y = run; run += v[4 * k + 1];
+         q.z = run; run += v[4 * k + 2];
+         q.w = run; run += v[4 * k + 3];
+         o[k] = q;
+         z[k] = make_uint4(0, 0, 0, 0);
+      }
+   } else {
+      for (int k = 0; k < SCAN_ITEMS; k++) {
+         if (base + k < ncells) {
+            cell_start[base + k] = run;
+            count[base + k] = 0;
+            run += v[k];
+         }
+      }
+   }
+   // the thread that owns the last cell also writes the end sentinel
+   if (base <= ncells - 1 && ncells - 1 < base + SCAN_ITEMS) cell_start[ncells] = run;
+}
+
+// ---- 3. scatter -----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
+          const uint32_t* __restrict__ cell_start, int n, uint32_t* __restrict__ perm)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
+}
+
+// ---- 4a. REF: ascending-index order inside each cell ---------------------------------------
+__global__ void __launch_bounds__(256)
+k_rank_order(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
+             const uint32_t* __restrict__ cell_start, int n, uint32_t* __restrict__ order)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= n) return;
+   const uint32_t i = perm[p];
+   const uint32_t c = key[i];
+   const uint32_t s = cell_start[c], e = cell_start[c + 1];
+   uint32_t rank = 0;
+   for (uint32_t q = s; q < e; q++) rank += (perm[q] < i) ? 1u : 0u;
+   order[s + rank] = i;
+}
+
+// ---- 4b. FULL: gather the state into cell-sorted order, ascending persistent id in a cell ----
+__global__ void __launch_bounds__(256)
+k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
+              const uint32_t* __restrict__ cell_start, int n, const float4* __restrict__ posm_in,
+              const float4* __restrict__ velp_in, float4* __restrict__ posm_out,
+              float4* __restrict__ velp_out)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= n) return;
+   const uint32_t i = perm[p];
+   const uint32_t c = key[i];
+   const uint32_t s = cell_start[c], e = cell_start[c + 1];
+   const float4 v = velp_in[i];
+   const uint32_t id = __float_as_uint(v.w);
+   uint32_t rank = 0;
+   for (uint32_t q = s; q < e; q++) {
+      const uint32_t other = __float_as_uint(velp_in[perm[q]].w);
+      rank += (other < id) ? 1u : 0u;
+   }
+   posm_out[s + rank] = posm_in[i];
+   velp_out[s + rank] = v;
+}

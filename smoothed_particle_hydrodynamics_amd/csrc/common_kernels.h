@@ -1,0 +1,181 @@
+// Kernels shared by both modes: integrate (+ energy totals), host-layout import/export,
+// neighbour-count statistics.
+#pragma once
+
+#include "pair_math.h"
+
+#define RED_THREADS 256
+
+// ---- integrate (reference src/sph.cpp:937-1022) -------------------------------------------------
+// "KDK as coded": half kick with the SPH acceleration, drift, then a FULL-dt kick with the
+// point-mass gravity only, evaluated at the new position.  KE/PE contributions are reduced per
+// block in double (the reference's serial fp32 running sum is order dependent).
+template <bool UNIT_SCALE>
+__global__ void __launch_bounds__(RED_THREADS)
+k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* __restrict__ acc,
+            int n, PairConsts k, double* __restrict__ epart)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   double ke = 0.0, pe = 0.0;
+   if (p < n) {
+      float4 x = posm[p];
+      float4 v = velp[p];
+      const float4 a = acc[p];
+      const float dt = k.dt;
+      const float pos_dt = dt * k.sim_scale_inv;
+
+      const float vhx = v.x + (a.x * dt * 0.5f);
+      const float vhy = v.y + (a.y * dt * 0.5f);
+      const float vhz = v.z + (a.z * dt * 0.5f);
+      const float nx = x.x + (vhx * pos_dt);
+      const float ny = x.y + (vhy * pos_dt);
+      const float nz = x.z + (vhz * pos_dt);
+
+      float rsx = (nx - k.cx), rsy = (ny - k.cy), rsz = (nz - k.cz);
+      if (!UNIT_SCALE) {
+         rsx *= k.sim_scale;
+         rsy *= k.sim_scale;
+         rsz *= k.sim_scale;
+      }
+      float dot = rsx * rsx + rsy * rsy + rsz * rsz;
+      dot = sqrtf(dot);
+      const float ds = dot + k.softening;
+      const float d3 = ds * ds * ds;
+      const float gm = -k.grav_const * k.central_mass;
+      const float nvx = vhx + ((gm * (rsx / d3)) * dt);
+      const float nvy = vhy + ((gm * (rsy / d3)) * dt);
+      const float nvz = vhz + ((gm * (rsz / d3)) * dt);
+
+      dot = nvx * nvx + nvy * nvy + nvz * nvz;
+      if (dot > 0) {
+         ke = (double)(0.5f * x.w * dot);
+         pe = -(double)(k.grav_const * k.central_mass * x.w / d3);
+      }
+      x.x = nx; x.y = ny; x.z = nz;
+      v.x = nvx; v.y = nvy; v.z = nvz;
+      posm[p] = x;
+      velp[p] = v;
+   }
+   // block reduction, fixed order
+   __shared__ double s_ke[RED_THREADS / SPH_WAVE], s_pe[RED_THREADS / SPH_WAVE];
+#pragma unroll
+   for (int d = SPH_WAVE / 2; d > 0; d >>= 1) {
+      ke += __shfl_down(ke, d);
+      pe += __shfl_down(pe, d);
+   }
+   const int lane = threadIdx.x & (SPH_WAVE - 1), w = threadIdx.x / SPH_WAVE;
+   if (lane == 0) {
+      s_ke[w] = ke;
+      s_pe[w] = pe;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int q = 0; q < RED_THREADS / SPH_WAVE; q++) {
+         a += s_ke[q];
+         b += s_pe[q];
+      }
+      epart[2 * blockIdx.x + 0] = a;
+      epart[2 * blockIdx.x + 1] = b;
+   }
+}
+
+// one block: totals of the per-block partials, written to out[0..1]
+__global__ void __launch_bounds__(RED_THREADS)
+k_energy_total(const double* __restrict__ epart, int nblocks, double* __restrict__ out)
+{
+   double ke = 0.0, pe = 0.0;
+   for (int b = threadIdx.x; b < nblocks; b += RED_THREADS) {
+      ke += epart[2 * b + 0];
+      pe += epart[2 * b + 1];
+   }
+   __shared__ double s_ke[RED_THREADS], s_pe[RED_THREADS];
+   s_ke[threadIdx.x] = ke;
+   s_pe[threadIdx.x] = pe;
+   __syncthreads();
+   for (int d = RED_THREADS / 2; d > 0; d >>= 1) {
+      if ((int)threadIdx.x < d) {
+         s_ke[threadIdx.x] += s_ke[threadIdx.x + d];
+         s_pe[threadIdx.x] += s_pe[threadIdx.x + d];
+      }
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) {
+      out[0] = s_ke[0];
+      out[1] = s_pe[0];
+   }
+}
+
+// ---- host layout <-> device layout --------------------------------------------------------------
+// stage holds the reference's arrays back to back: pos[3n] vel[3n] mass[n]
+__global__ void __launch_bounds__(256)
+k_import(const float* __restrict__ pos, const float* __restrict__ vel,
+         const float* __restrict__ mass, int n, float4* __restrict__ posm,
+         float4* __restrict__ velp)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   posm[i] = make_float4(pos[3 * i + 0], pos[3 * i + 1], pos[3 * i + 2], mass[i]);
+   velp[i] = make_float4(vel[3 * i + 0], vel[3 * i + 1], vel[3 * i + 2], __uint_as_float((uint32_t)i));
+}
+
+// scatter by persistent id into pos[3n] vel[3n] rho[n] acc[3n] ncount[n] (any may be null)
+__global__ void __launch_bounds__(256)
+k_export(const float4* __restrict__ posm, const float4* __restrict__ velp,
+         const float* __restrict__ rho, const float4* __restrict__ acc,
+         const int32_t* __restrict__ ncount, int n, float* __restrict__ pos,
+         float* __restrict__ vel, float* __restrict__ orho, float* __restrict__ oacc,
+         int32_t* __restrict__ ocount)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= n) return;
+   const float4 v = velp[p];
+   const uint32_t id = __float_as_uint(v.w);
+   if (pos) {
+      const float4 x = posm[p];
+      pos[3 * id + 0] = x.x;
+      pos[3 * id + 1] = x.y;
+      pos[3 * id + 2] = x.z;
+   }
+   if (vel) {
+      vel[3 * id + 0] = v.x;
+      vel[3 * id + 1] = v.y;
+      vel[3 * id + 2] = v.z;
+   }
+   if (orho) orho[id] = rho[p];
+   if (oacc) {
+      const float4 a = acc[p];
+      oacc[3 * id + 0] = a.x;
+      oacc[3 * id + 1] = a.y;
+      oacc[3 * id + 2] = a.z;
+   }
+   if (ocount) ocount[id] = ncount[p];
+}
+
+// ---- neighbour statistics (reference src/sph.cpp:204-232) -----------------------------------------
+// out: [0] = sum low 32, [1] = sum high 32 (as one 64-bit add), [2] = max, [3] = min (from 34)
+__global__ void __launch_bounds__(RED_THREADS)
+k_neighbor_stats(const int32_t* __restrict__ ncount, int n, int32_t* __restrict__ out)
+{
+   long long sum = 0;
+   int mx = -1, mn = 34;
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int c = ncount[i];
+      sum += c;
+      mx = c > mx ? c : mx;
+      mn = c < mn ? c : mn;
+   }
+#pragma unroll
+   for (int d = SPH_WAVE / 2; d > 0; d >>= 1) {
+      sum += __shfl_down(sum, d);
+      const int omx = __shfl_down(mx, d), omn = __shfl_down(mn, d);
+      mx = omx > mx ? omx : mx;
+      mn = omn < mn ? omn : mn;
+   }
+   if ((threadIdx.x & (SPH_WAVE - 1)) == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)sum);
+      atomicMax(out + 2, mx);
+      atomicMin(out + 3, mn);
+   }
+}

@@ -1,0 +1,120 @@
+// Per-pair and per-particle arithmetic of the reference's sums, as device inlines.
+//
+// Every expression keeps the reference's association and rounding points so that results are
+// bit-identical to the x86-64 IEEE build of src/sph.cpp (this translation unit is compiled with
+// -ffp-contract=off; sqrtf and '/' are correctly rounded under hipcc's defaults).
+#pragma once
+
+#include "sph_device.h"
+
+// computeDensity's inner term (reference src/sph.cpp:744-761).  d is the stored distance.
+__device__ __forceinline__ void density_accumulate(const PairConsts& k, float mass, float d,
+                                                   float& density)
+{
+   if (!(d > k.hscaled)) {
+      float t = (k.hscaled2 - (d * d));
+      t = (t * t * t);
+      const float w = k.kernel1 * t;
+      density += (mass * w);
+   }
+}
+
+// Quantities of neighbour j that computeAcceleration re-derives for every pair
+// (reference src/sph.cpp:829-834, 860, 871).  They depend on j only, so they are computed once
+// per particle after the density pass: B = p_j * rhojInv^2, C = (rhojInv * m_j) * k3.
+__device__ __forceinline__ float2 neighbor_terms(const PairConsts& k, float rho_j, float m_j)
+{
+   const float pj = (rho_j - k.rho0) * k.stiffness;
+   const float rhoj_inv = ((rho_j > 0.0f) ? (1.0f / rho_j) : 1.0f);
+   const float rhoj_inv2 = rhoj_inv * rhoj_inv;
+   return make_float2(pj * rhoj_inv2, rhoj_inv * m_j * k.kernel3);
+}
+
+struct AccelState {
+   float rhoi_inv, pi_div_rhoi2, visc_scale;
+   float rx, ry, rz, vx, vy, vz;
+   float pgx, pgy, pgz, vtx, vty, vtz;
+};
+
+// reference src/sph.cpp:785-798
+__device__ __forceinline__ void accel_begin(const PairConsts& k, AccelState& s, float4 posm,
+                                            float4 velp, float rho_i)
+{
+   const float pi = (rho_i - k.rho0) * k.stiffness;
+   s.rhoi_inv = ((pi > 0.0f) ? (1.0f / pi) : 1.0f); // derived from the PRESSURE, as shipped
+   const float rhoi_inv2 = s.rhoi_inv * s.rhoi_inv;
+   s.pi_div_rhoi2 = pi * rhoi_inv2;
+   s.visc_scale = k.viscosity * s.rhoi_inv;
+   s.rx = posm.x; s.ry = posm.y; s.rz = posm.z;
+   s.vx = velp.x; s.vy = velp.y; s.vz = velp.z;
+   s.pgx = s.pgy = s.pgz = 0.0f;
+   s.vtx = s.vty = s.vtz = 0.0f;
+}
+
+// One neighbour (reference src/sph.cpp:846-882).  (dx,dy,dz) = r_i - r_j, d = stored distance,
+// B/C from neighbor_terms().
+template <bool UNIT_SCALE>
+__device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, float dx, float dy,
+                                           float dz, float d, float mj, float vjx, float vjy,
+                                           float vjz, float B, float C)
+{
+   const float rsx = UNIT_SCALE ? dx : dx * k.sim_scale;
+   const float rsy = UNIT_SCALE ? dy : dy * k.sim_scale;
+   const float rsz = UNIT_SCALE ? dz : dz * k.sim_scale;
+   // float product, double add, double divide, narrowed to float (:854-856)
+   const double den = (double)d + 0.01;
+   const float gx = (float)((double)(k.kernel2 * rsx) / den);
+   const float gy = (float)((double)(k.kernel2 * rsy) / den);
+   const float gz = (float)((double)(k.kernel2 * rsz) / den);
+
+   float center = (k.hscaled - d);
+   center *= center;
+   center *= mj * s.pi_div_rhoi2 * B; // (m_j * A) * (p_j * rhojInv^2), :860
+   s.pgx += gx * center;
+   s.pgy += gy * center;
+   s.pgz += gz * center;
+
+   center = (k.hscaled - d);
+   center *= C;
+   s.vtx += (vjx - s.vx) * center;
+   s.vty += (vjy - s.vy) * center;
+   s.vtz += (vjz - s.vz) * center;
+   // the rescale sits inside the neighbour loop (:880-882)
+   s.vtx *= s.visc_scale;
+   s.vty *= s.visc_scale;
+   s.vtz *= s.visc_scale;
+}
+
+// reference src/sph.cpp:888-933
+template <bool UNIT_SCALE>
+__device__ __forceinline__ float4 accel_end(const PairConsts& k, const AccelState& s)
+{
+   float ax = s.vtx - s.pgx;
+   float ay = s.vty - s.pgy;
+   float az = s.vtz - s.pgz;
+
+   float rsx = (s.rx - k.cx), rsy = (s.ry - k.cy), rsz = (s.rz - k.cz);
+   if (!UNIT_SCALE) {
+      rsx *= k.sim_scale;
+      rsy *= k.sim_scale;
+      rsz *= k.sim_scale;
+   }
+   float dot = (rsx * rsx) + (rsy * rsy) + (rsz * rsz);
+   dot = sqrtf(dot);
+   const float ds = dot + k.softening;
+   const float d3 = ds * ds * ds;
+   const float gm = -k.grav_const * k.central_mass;
+   ax += gm * (rsx / d3);
+   ay += gm * (rsy / d3);
+   az += gm * (rsz / d3);
+
+   dot = (ax * ax) + (ay * ay) + (az * az);
+   if (dot > k.cfl_limit2) {
+      const float length = sqrtf(dot);
+      const float scale = k.cfl_limit / length;
+      ax *= scale;
+      ay *= scale;
+      az *= scale;
+   }
+   return make_float4(ax, ay, az, 0.0f);
+}

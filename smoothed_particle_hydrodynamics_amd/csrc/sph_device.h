@@ -1,0 +1,131 @@
+// Shared device-side helpers and the context layout of the gfx950 SPH step.
+// Written for MI355X only: wave = 64 lanes, no other targets, no compatibility paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/sph_hip.h"
+
+#define SPH_WAVE 64
+#define EV_RING 128
+
+// ---- error plumbing -------------------------------------------------------------------
+#define SPH_TRY(expr)                                                                \
+   do {                                                                              \
+      hipError_t e_ = (expr);                                                        \
+      if (e_ != hipSuccess) {                                                        \
+         ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+         return SPH_HIP_ERR_DEVICE;                                                  \
+      }                                                                              \
+   } while (0)
+
+// Grid description handed to kernels by value.
+struct CellGrid {
+   int nx, ny, nz;
+   float inv;  // cells per unit length
+   int ncells;
+};
+
+// Constants of the per-pair arithmetic, by value in kernarg (scalar registers).
+struct PairConsts {
+   float h2, hscaled, hscaled2, sim_scale;
+   float kernel1, kernel2, kernel3;
+   float rho0, stiffness, viscosity;
+   float grav_const, central_mass, cx, cy, cz, softening;
+   float cfl_limit, cfl_limit2;
+   float dt, sim_scale_inv;
+};
+
+struct sph_hip_context {
+   sph_hip_params prm;
+   int mode = 0;
+   int device = 0;
+   int capacity = 0;
+   int n = 0;       // particles resident (owned + ghosts)
+   int n_owned = 0; // particles integrated / downloaded
+   hipStream_t stream = nullptr;
+   // per-phase event ring: EV_RING steps x 7 events; `ev_steps` counts timed steps since the
+   // last reset (phase totals cover the last min(ev_steps, EV_RING) of them)
+   hipEvent_t* ev = nullptr;
+   long long ev_steps = 0;
+   std::string err;
+
+   CellGrid grid;
+
+   // particle state: {x,y,z,m} and {vx,vy,vz,id-bits}.  FULL mode keeps it cell-sorted and
+   // ping-pongs between the two buffers at every cell build; REF mode keeps it in index order
+   // in buffer 0.
+   float4* posm[2] = {nullptr, nullptr};
+   float4* velp[2] = {nullptr, nullptr};
+   int cur = 0;
+
+   // cell build
+   uint32_t* key = nullptr;        // cell id per particle
+   uint32_t* slot = nullptr;       // arrival rank inside the cell (from the counting atomic)
+   uint32_t* perm = nullptr;       // cell-sorted, arbitrary order inside a cell
+   uint32_t* order = nullptr;      // REF: cell-sorted, ascending index inside a cell
+   uint32_t* cell_count = nullptr; // ncells
+   uint32_t* cell_start = nullptr; // ncells + 1
+   uint32_t* scan_part = nullptr;  // per-tile partial sums of the scan
+   int scan_tiles = 0;
+
+   // sums
+   float* rho = nullptr;
+   float2* aux = nullptr; // per particle {p_j * rhojInv^2, (rhojInv * m_j) * k3}
+   float4* acc = nullptr; // {ax, ay, az, unused}
+   int32_t* ncount = nullptr;
+
+   // REF-mode lists
+   int32_t* vox = nullptr; // 3 ints per particle
+   uint32_t* nb = nullptr;
+   float* nd = nullptr;
+
+   // reductions
+   double* epart = nullptr; // 2 * blocks partial sums, then [0],[1] totals
+   int eblocks = 0;
+   int32_t* stats = nullptr; // sum(lo,hi), max, min
+
+   // staging for host <-> device in the reference's interleaved layouts
+   float* stage = nullptr; // capacity * 11 floats
+};
+
+// ---- arithmetic helpers -----------------------------------------------------------------
+
+// (int)floor(x) the way the x86-64 reference build does it (cvttsd2si): out-of-range and NaN
+// give INT_MIN, which the clamp that follows turns into cell 0.
+__device__ __forceinline__ int floor_to_int_x86(float f)
+{
+   float fl = floorf(f);
+   return (fl >= -2147483648.0f && fl < 2147483648.0f) ? (int)fl : (int)0x80000000;
+}
+
+__device__ __forceinline__ int cell_coord(float x, float inv, int ncell)
+{
+   int c = floor_to_int_x86(x * inv);
+   c = c < 0 ? 0 : c;
+   c = c >= ncell ? ncell - 1 : c;
+   return c;
+}
+
+__device__ __forceinline__ uint32_t cell_of(const CellGrid& g, float x, float y, float z, int& cx,
+                                           int& cy, int& cz)
+{
+   cx = cell_coord(x, g.inv, g.nx);
+   cy = cell_coord(y, g.inv, g.ny);
+   cz = cell_coord(z, g.inv, g.nz);
+   return (uint32_t)((cz * g.ny + cy) * g.nx + cx);
+}
+
+// fp32 squared distance with the reference's association: (dx*dx + dy*dy) + dz*dz, no FMA
+// (the translation unit is compiled with -ffp-contract=off).
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz,
+                                       float& dx, float& dy, float& dz)
+{
+   dx = ax - bx;
+   dy = ay - by;
+   dz = az - bz;
+   return dx * dx + dy * dy + dz * dz;
+}

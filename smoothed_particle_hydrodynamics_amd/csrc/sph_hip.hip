@@ -1,0 +1,660 @@
+// C ABI of the gfx950 SPH step (include/sph_hip.h) — context management and phase launches.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "cell_build.h"
+#include "common_kernels.h"
+#include "full_kernels.h"
+#include "ref_kernels.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+std::string g_create_error;
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+PairConsts pair_consts(const sph_hip_params& p)
+{
+   PairConsts k;
+   k.h2 = p.h2;
+   k.hscaled = p.hscaled;
+   k.hscaled2 = p.hscaled2;
+   k.sim_scale = p.sim_scale;
+   k.kernel1 = p.kernel1;
+   k.kernel2 = p.kernel2;
+   k.kernel3 = p.kernel3;
+   k.rho0 = p.rho0;
+   k.stiffness = p.stiffness;
+   k.viscosity = p.viscosity;
+   k.grav_const = p.grav_const;
+   k.central_mass = p.central_mass;
+   k.cx = p.central_pos[0];
+   k.cy = p.central_pos[1];
+   k.cz = p.central_pos[2];
+   k.softening = p.softening;
+   k.cfl_limit = p.cfl_limit;
+   k.cfl_limit2 = p.cfl_limit2;
+   k.dt = p.time_step;
+   k.sim_scale_inv = p.sim_scale_inv;
+   return k;
+}
+
+bool unit_scale(const sph_hip_params& p) { return p.sim_scale == 1.0f && p.sim_scale_inv == 1.0f; }
+
+template <typename T>
+hipError_t dev_alloc(T** ptr, size_t count)
+{
+   return hipMalloc(reinterpret_cast<void**>(ptr), count * sizeof(T));
+}
+
+void free_all(sph_hip_context* ctx)
+{
+   for (int b = 0; b < 2; b++) {
+      if (ctx->posm[b]) (void)hipFree(ctx->posm[b]);
+      if (ctx->velp[b]) (void)hipFree(ctx->velp[b]);
+   }
+   void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
+                   ctx->scan_part, ctx->rho, ctx->aux, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
+                   ctx->nd, ctx->epart, ctx->stats, ctx->stage};
+   for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+   if (ctx->ev) {
+      for (int k = 0; k < EV_RING * 7; k++)
+         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+      delete[] ctx->ev;
+   }
+   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+}
+
+int check_ctx(sph_hip_context* ctx)
+{
+   if (!ctx) return SPH_HIP_ERR_INVALID;
+   hipError_t e = hipSetDevice(ctx->device);
+   if (e != hipSuccess) {
+      ctx->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+      return SPH_HIP_ERR_DEVICE;
+   }
+   return SPH_HIP_OK;
+}
+
+// ---- phase launches (no event recording, no host sync) ---------------------------------------
+
+int launch_cell_build(sph_hip_context* ctx)
+{
+   const int n = ctx->n;
+   if (n == 0) return SPH_HIP_OK;
+   const int blocks = div_up(n, 256);
+   const CellGrid g = ctx->grid;
+   hipStream_t st = ctx->stream;
+   const float4* posm = ctx->posm[ctx->cur];
+   if (ctx->mode == SPH_HIP_MODE_REF)
+      hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, posm, n, g, ctx->key,
+                         ctx->slot, ctx->cell_count, ctx->vox);
+   else
+      hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, posm, n, g, ctx->key,
+                         ctx->slot, ctx->cell_count, (int32_t*)nullptr);
+   const int tiles = ctx->scan_tiles;
+   hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
+                      g.ncells, ctx->scan_part);
+   hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(SCAN_THREADS), 0, st, ctx->scan_part, tiles);
+   hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
+                      g.ncells, ctx->scan_part, ctx->cell_start);
+   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
+                      ctx->cell_start, n, ctx->perm);
+   if (ctx->mode == SPH_HIP_MODE_REF) {
+      hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
+                         ctx->cell_start, n, ctx->order);
+   } else {
+      const int nxt = ctx->cur ^ 1;
+      hipLaunchKernelGGL(k_rank_gather, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
+                         ctx->cell_start, n, ctx->posm[ctx->cur], ctx->velp[ctx->cur],
+                         ctx->posm[nxt], ctx->velp[nxt]);
+      ctx->cur = nxt;
+   }
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int launch_find_neighbors(sph_hip_context* ctx)
+{
+   if (ctx->mode != SPH_HIP_MODE_REF || ctx->n == 0) return SPH_HIP_OK;
+   const sph_hip_params& p = ctx->prm;
+   hipLaunchKernelGGL(k_ref_find_neighbors, dim3(div_up(ctx->n, 256)), dim3(256), 0, ctx->stream,
+                      ctx->posm[0], ctx->vox, ctx->cell_start, ctx->order, ctx->n, p.cells_x,
+                      p.cells_y, p.cells_z, p.h, p.htimes2, p.h2, p.sim_scale, p.examine_count,
+                      ctx->nb, ctx->nd, ctx->ncount);
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int launch_density(sph_hip_context* ctx)
+{
+   const int n = ctx->n;
+   if (n == 0) return SPH_HIP_OK;
+   const PairConsts k = pair_consts(ctx->prm);
+   const int blocks = div_up(n, 256);
+   if (ctx->mode == SPH_HIP_MODE_REF) {
+      hipLaunchKernelGGL(k_ref_density, dim3(blocks), dim3(256), 0, ctx->stream, ctx->posm[0],
+                         ctx->nb, ctx->nd, ctx->ncount, n, ctx->prm.examine_count, k, ctx->rho);
+   } else if (unit_scale(ctx->prm)) {
+      hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho, ctx->aux,
+                         ctx->ncount);
+   } else {
+      hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho, ctx->aux,
+                         ctx->ncount);
+   }
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int launch_accel(sph_hip_context* ctx)
+{
+   const int n = ctx->n;
+   if (n == 0) return SPH_HIP_OK;
+   const PairConsts k = pair_consts(ctx->prm);
+   const int blocks = div_up(n, 256);
+   if (ctx->mode == SPH_HIP_MODE_REF) {
+      hipLaunchKernelGGL(k_ref_accel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->posm[0],
+                         ctx->velp[0], ctx->rho, ctx->nb, ctx->nd, ctx->ncount, n,
+                         ctx->prm.examine_count, k, ctx->acc);
+   } else if (unit_scale(ctx->prm)) {
+      hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
+                         ctx->cell_start, n, ctx->grid, k, ctx->acc);
+   } else {
+      hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
+                         ctx->cell_start, n, ctx->grid, k, ctx->acc);
+   }
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int launch_integrate(sph_hip_context* ctx)
+{
+   const int n = ctx->n_owned;
+   if (n == 0) return SPH_HIP_OK;
+   const PairConsts k = pair_consts(ctx->prm);
+   const int blocks = div_up(n, RED_THREADS);
+   if (unit_scale(ctx->prm))
+      hipLaunchKernelGGL(k_integrate<true>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, n, k, ctx->epart + 2);
+   else
+      hipLaunchKernelGGL(k_integrate<false>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, n, k, ctx->epart + 2);
+   hipLaunchKernelGGL(k_energy_total, dim3(1), dim3(RED_THREADS), 0, ctx->stream, ctx->epart + 2,
+                      blocks, ctx->epart);
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int step_impl(sph_hip_context* ctx, bool timed)
+{
+   int rc;
+   hipStream_t st = ctx->stream;
+   hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
+   if (timed) SPH_TRY(hipEventRecord(ev[0], st));
+   if ((rc = launch_cell_build(ctx))) return rc;
+   if (timed) SPH_TRY(hipEventRecord(ev[1], st));
+   if ((rc = launch_find_neighbors(ctx))) return rc;
+   if (timed) SPH_TRY(hipEventRecord(ev[2], st));
+   if ((rc = launch_density(ctx))) return rc;
+   if (timed) SPH_TRY(hipEventRecord(ev[3], st));
+   // (computePressure is a no-op in the reference, src/sph.cpp:253-263)
+   if (timed) SPH_TRY(hipEventRecord(ev[4], st));
+   if ((rc = launch_accel(ctx))) return rc;
+   if (timed) SPH_TRY(hipEventRecord(ev[5], st));
+   if ((rc = launch_integrate(ctx))) return rc;
+   if (timed) SPH_TRY(hipEventRecord(ev[6], st));
+   if (timed) ctx->ev_steps++;
+   return SPH_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sph_hip_params_default(sph_hip_params* p, float h, int cells_x, int cells_y, int cells_z)
+{
+   if (!p || !(h > 0.0f) || cells_x < 1 || cells_y < 1 || cells_z < 1) return SPH_HIP_ERR_INVALID;
+   memset(p, 0, sizeof(*p));
+   // reference src/sph.cpp:46-98, same order, same rounding points
+   p->sim_scale = 1.0f;
+   p->sim_scale_inv = 1.0f / p->sim_scale;
+   p->h = h;
+   p->h2 = (float)pow((double)h, 2.0);
+   p->htimes2 = h * 2.0f;
+   p->htimes2inv = 1.0f / p->htimes2;
+   p->hscaled = h * p->sim_scale;
+   p->hscaled2 = (float)pow((double)(h * p->sim_scale), 2.0);
+   p->hscaled6 = (float)pow((double)(h * p->sim_scale), 6.0);
+   p->hscaled9 = (float)pow((double)(h * p->sim_scale), 9.0);
+   p->cells_x = cells_x;
+   p->cells_y = cells_y;
+   p->cells_z = cells_z;
+   p->cell_size = 2.0f * h;
+   p->max_x = p->cell_size * (float)cells_x;
+   p->max_y = p->cell_size * (float)cells_y;
+   p->max_z = p->cell_size * (float)cells_z;
+   p->time_step = 0.001f;
+   p->rho0 = 0.1f;
+   p->stiffness = 0.001f;
+   p->viscosity = 0.01f;
+   p->damping = 0.001f;
+   p->grav_const = 4.3009e-3f;
+   p->central_mass = 1e+5f;
+   p->central_pos[0] = p->max_x * 0.5f;
+   p->central_pos[1] = p->max_y * 0.5f;
+   p->central_pos[2] = p->max_z * 0.5f;
+   p->softening = p->hscaled;
+   p->cfl_limit = 10000.0f;
+   p->cfl_limit2 = p->cfl_limit * p->cfl_limit;
+   p->kernel1 = 315.0f / (64.0f * (float)(M_PI)*p->hscaled9);
+   p->kernel2 = -45.0f / ((float)(M_PI)*p->hscaled6);
+   p->kernel3 = -p->kernel2;
+   p->examine_count = 32;
+   // FULL grid: cell edge h*(1+1e-4) >= h, covering the same box
+   const double edge = (double)h * 1.0001;
+   p->full_cell_inv = (float)(1.0 / edge);
+   p->full_cells_x = (int)ceil((double)p->max_x / edge);
+   p->full_cells_y = (int)ceil((double)p->max_y / edge);
+   p->full_cells_z = (int)ceil((double)p->max_z / edge);
+   return SPH_HIP_OK;
+}
+
+int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
+                   int device)
+{
+   if (!out || !params || capacity < 1 || (mode != SPH_HIP_MODE_REF && mode != SPH_HIP_MODE_FULL)) {
+      g_create_error = "sph_hip_create: invalid argument";
+      return SPH_HIP_ERR_INVALID;
+   }
+   *out = nullptr;
+   int ndev = 0;
+   hipError_t e = hipGetDeviceCount(&ndev);
+   if (e != hipSuccess || ndev == 0 || device < 0 || device >= ndev) {
+      g_create_error = "sph_hip_create: no usable HIP device (" +
+                       std::string(e != hipSuccess ? hipGetErrorString(e) : "device index out of range") + ")";
+      return SPH_HIP_ERR_NO_DEVICE;
+   }
+   sph_hip_context* ctx = new (std::nothrow) sph_hip_context();
+   if (!ctx) return SPH_HIP_ERR_INVALID;
+   ctx->prm = *params;
+   ctx->mode = mode;
+   ctx->device = device;
+   ctx->capacity = capacity;
+
+   CellGrid& g = ctx->grid;
+   if (mode == SPH_HIP_MODE_REF) {
+      g.nx = params->cells_x; g.ny = params->cells_y; g.nz = params->cells_z;
+      g.inv = params->htimes2inv;
+   } else {
+      g.nx = params->full_cells_x; g.ny = params->full_cells_y; g.nz = params->full_cells_z;
+      g.inv = params->full_cell_inv;
+   }
+   const long long ncells = (long long)g.nx * g.ny * g.nz;
+   if (g.nx < 1 || g.ny < 1 || g.nz < 1 || ncells > 0x7fff0000ll) {
+      g_create_error = "sph_hip_create: bad grid shape";
+      delete ctx;
+      return SPH_HIP_ERR_INVALID;
+   }
+   g.ncells = (int)ncells;
+   ctx->scan_tiles = div_up(g.ncells, SCAN_TILE);
+   ctx->eblocks = div_up(capacity, RED_THREADS);
+
+   auto fail = [&](const char* what, hipError_t err) {
+      g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+      free_all(ctx);
+      delete ctx;
+      return SPH_HIP_ERR_DEVICE;
+   };
+#define CREATE_TRY(expr)                                   \
+   do {                                                    \
+      hipError_t e_ = (expr);                              \
+      if (e_ != hipSuccess) return fail(#expr, e_);        \
+   } while (0)
+
+   CREATE_TRY(hipSetDevice(device));
+   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+   ctx->ev = new hipEvent_t[EV_RING * 7]();
+   for (int k = 0; k < EV_RING * 7; k++) CREATE_TRY(hipEventCreate(&ctx->ev[k]));
+   const size_t cap = (size_t)capacity;
+   const int nbuf = (mode == SPH_HIP_MODE_FULL) ? 2 : 1;
+   for (int b = 0; b < nbuf; b++) {
+      CREATE_TRY(dev_alloc(&ctx->posm[b], cap));
+      CREATE_TRY(dev_alloc(&ctx->velp[b], cap));
+   }
+   CREATE_TRY(dev_alloc(&ctx->key, cap));
+   CREATE_TRY(dev_alloc(&ctx->slot, cap));
+   CREATE_TRY(dev_alloc(&ctx->perm, cap));
+   // cell arrays padded to whole scan tiles so vector accesses never run off the end
+   const size_t cells_padded = (size_t)ctx->scan_tiles * SCAN_TILE + 16;
+   CREATE_TRY(dev_alloc(&ctx->cell_count, cells_padded));
+   CREATE_TRY(dev_alloc(&ctx->cell_start, cells_padded));
+   CREATE_TRY(dev_alloc(&ctx->scan_part, (size_t)ctx->scan_tiles + 1));
+   CREATE_TRY(hipMemsetAsync(ctx->cell_count, 0, cells_padded * sizeof(uint32_t), ctx->stream));
+   CREATE_TRY(dev_alloc(&ctx->rho, cap));
+   CREATE_TRY(dev_alloc(&ctx->acc, cap));
+   CREATE_TRY(dev_alloc(&ctx->ncount, cap));
+   CREATE_TRY(hipMemsetAsync(ctx->rho, 0, cap * sizeof(float), ctx->stream));
+   CREATE_TRY(hipMemsetAsync(ctx->acc, 0, cap * sizeof(float4), ctx->stream));
+   CREATE_TRY(hipMemsetAsync(ctx->ncount, 0, cap * sizeof(int32_t), ctx->stream));
+   if (mode == SPH_HIP_MODE_FULL) {
+      CREATE_TRY(dev_alloc(&ctx->aux, cap));
+   } else {
+      CREATE_TRY(dev_alloc(&ctx->order, cap));
+      CREATE_TRY(dev_alloc(&ctx->vox, cap * 3));
+      CREATE_TRY(dev_alloc(&ctx->nb, cap * (size_t)params->examine_count));
+      CREATE_TRY(dev_alloc(&ctx->nd, cap * (size_t)params->examine_count));
+   }
+   CREATE_TRY(dev_alloc(&ctx->epart, (size_t)2 * ctx->eblocks + 2));
+   CREATE_TRY(hipMemsetAsync(ctx->epart, 0, sizeof(double) * 2, ctx->stream));
+   CREATE_TRY(dev_alloc(&ctx->stats, 4));
+   CREATE_TRY(dev_alloc(&ctx->stage, cap * 11));
+   CREATE_TRY(hipStreamSynchronize(ctx->stream));
+#undef CREATE_TRY
+   *out = ctx;
+   return SPH_HIP_OK;
+}
+
+void sph_hip_destroy(sph_hip_context* ctx)
+{
+   if (!ctx) return;
+   (void)hipSetDevice(ctx->device);
+   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+   free_all(ctx);
+   delete ctx;
+}
+
+const char* sph_hip_last_error(const sph_hip_context* ctx)
+{
+   return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int sph_hip_set_params(sph_hip_context* ctx, const sph_hip_params* p)
+{
+   if (!ctx || !p) return SPH_HIP_ERR_INVALID;
+   const sph_hip_params& o = ctx->prm;
+   if (p->cells_x != o.cells_x || p->cells_y != o.cells_y || p->cells_z != o.cells_z ||
+       p->full_cells_x != o.full_cells_x || p->full_cells_y != o.full_cells_y ||
+       p->full_cells_z != o.full_cells_z || p->h != o.h || p->htimes2inv != o.htimes2inv ||
+       p->full_cell_inv != o.full_cell_inv || p->examine_count != o.examine_count) {
+      ctx->err = "sph_hip_set_params: grid shape, h and examine_count are fixed at creation";
+      return SPH_HIP_ERR_INVALID;
+   }
+   ctx->prm = *p;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_params(const sph_hip_context* ctx, sph_hip_params* out)
+{
+   if (!ctx || !out) return SPH_HIP_ERR_INVALID;
+   *out = ctx->prm;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_upload(sph_hip_context* ctx, int n, const float* pos, const float* vel,
+                   const float* mass)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (n < 0 || !pos || !vel || !mass) {
+      ctx->err = "sph_hip_upload: null array or negative count";
+      return SPH_HIP_ERR_INVALID;
+   }
+   if (n > ctx->capacity) {
+      ctx->err = "sph_hip_upload: more particles than the context capacity";
+      return SPH_HIP_ERR_CAPACITY;
+   }
+   ctx->n = n;
+   ctx->n_owned = n;
+   ctx->cur = 0;
+   ctx->ev_steps = 0;
+   if (n == 0) return SPH_HIP_OK;
+   float* spos = ctx->stage;
+   float* svel = spos + 3 * (size_t)n;
+   float* smass = svel + 3 * (size_t)n;
+   SPH_TRY(hipMemcpyAsync(spos, pos, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+   SPH_TRY(hipMemcpyAsync(svel, vel, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+   SPH_TRY(hipMemcpyAsync(smass, mass, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+   hipLaunchKernelGGL(k_import, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, spos, svel, smass,
+                      n, ctx->posm[0], ctx->velp[0]);
+   SPH_TRY(hipGetLastError());
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_download(sph_hip_context* ctx, float* pos, float* vel, float* density, float* acc,
+                     int32_t* neighbor_count)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   const int n = ctx->n_owned;
+   if (n == 0) return SPH_HIP_OK;
+   float* spos = ctx->stage;
+   float* svel = spos + 3 * (size_t)n;
+   float* srho = svel + 3 * (size_t)n;
+   float* sacc = srho + (size_t)n;
+   int32_t* scnt = reinterpret_cast<int32_t*>(sacc + 3 * (size_t)n);
+   hipLaunchKernelGGL(k_export, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream,
+                      ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->acc, ctx->ncount, n,
+                      pos ? spos : nullptr, vel ? svel : nullptr, density ? srho : nullptr,
+                      acc ? sacc : nullptr, neighbor_count ? scnt : nullptr);
+   SPH_TRY(hipGetLastError());
+   hipStream_t st = ctx->stream;
+   if (pos) SPH_TRY(hipMemcpyAsync(pos, spos, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+   if (vel) SPH_TRY(hipMemcpyAsync(vel, svel, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+   if (density) SPH_TRY(hipMemcpyAsync(density, srho, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+   if (acc) SPH_TRY(hipMemcpyAsync(acc, sacc, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+   if (neighbor_count)
+      SPH_TRY(hipMemcpyAsync(neighbor_count, scnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+   SPH_TRY(hipStreamSynchronize(st));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_particle_count(const sph_hip_context* ctx) { return ctx ? ctx->n_owned : 0; }
+
+int sph_hip_step(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   return step_impl(ctx, true);
+}
+
+int sph_hip_run(sph_hip_context* ctx, int steps)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   for (int s = 0; s < steps; s++)
+      if ((rc = step_impl(ctx, false))) return rc;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_voxelize(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   return rc ? rc : launch_cell_build(ctx);
+}
+
+int sph_hip_find_neighbors(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   return rc ? rc : launch_find_neighbors(ctx);
+}
+
+int sph_hip_compute_density(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   return rc ? rc : launch_density(ctx);
+}
+
+int sph_hip_compute_acceleration(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   return rc ? rc : launch_accel(ctx);
+}
+
+int sph_hip_integrate(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   return rc ? rc : launch_integrate(ctx);
+}
+
+int sph_hip_synchronize(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_timings(sph_hip_context* ctx, float ms[6])
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (!ms) return SPH_HIP_ERR_INVALID;
+   if (ctx->ev_steps == 0) {
+      ctx->err = "sph_hip_get_timings: no sph_hip_step() has run since the last upload/reset";
+      return SPH_HIP_ERR_INVALID;
+   }
+   hipEvent_t* ev = ctx->ev + 7 * ((ctx->ev_steps - 1) % EV_RING);
+   SPH_TRY(hipEventSynchronize(ev[6]));
+   for (int k = 0; k < 6; k++) SPH_TRY(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_reset_timings(sph_hip_context* ctx)
+{
+   if (!ctx) return SPH_HIP_ERR_INVALID;
+   ctx->ev_steps = 0;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_phase_totals(sph_hip_context* ctx, double ms[6], int32_t* steps)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (!ms || !steps) return SPH_HIP_ERR_INVALID;
+   const long long have = ctx->ev_steps < EV_RING ? ctx->ev_steps : EV_RING;
+   for (int k = 0; k < 6; k++) ms[k] = 0.0;
+   for (long long s = ctx->ev_steps - have; s < ctx->ev_steps; s++) {
+      hipEvent_t* ev = ctx->ev + 7 * (s % EV_RING);
+      SPH_TRY(hipEventSynchronize(ev[6]));
+      for (int k = 0; k < 6; k++) {
+         float t = 0.0f;
+         SPH_TRY(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+         ms[k] += (double)t;
+      }
+   }
+   *steps = (int32_t)have;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_energy(sph_hip_context* ctx, float* kinetic, float* potential)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   double e[2] = {0.0, 0.0};
+   SPH_TRY(hipMemcpyAsync(e, ctx->epart, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   if (kinetic) *kinetic = (float)e[0];
+   if (potential) *potential = (float)e[1];
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_neighbor_stats(sph_hip_context* ctx, int32_t* avg, int32_t* mx, int32_t* mn)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   const int n = ctx->n_owned;
+   if (n == 0) return SPH_HIP_ERR_INVALID;
+   const int32_t init[4] = {0, 0, -1, 34};
+   SPH_TRY(hipMemcpyAsync(ctx->stats, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+   int blocks = div_up(n, RED_THREADS);
+   if (blocks > 1024) blocks = 1024;
+   hipLaunchKernelGGL(k_neighbor_stats, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
+                      ctx->ncount, n, ctx->stats);
+   SPH_TRY(hipGetLastError());
+   int32_t out[4];
+   SPH_TRY(hipMemcpyAsync(out, ctx->stats, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   const long long sum = ((long long)(uint32_t)out[1] << 32) | (uint32_t)out[0];
+   if (avg) *avg = (int32_t)(sum / n);
+   if (mx) *mx = out[2];
+   if (mn) *mn = out[3];
+   return SPH_HIP_OK;
+}
+
+int sph_hip_download_voxels(sph_hip_context* ctx, int32_t* coords_xyz, int32_t* ids)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_REF) {
+      ctx->err = "sph_hip_download_voxels: REF-mode contexts only";
+      return SPH_HIP_ERR_INVALID;
+   }
+   const int n = ctx->n;
+   if (coords_xyz)
+      SPH_TRY(hipMemcpyAsync(coords_xyz, ctx->vox, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost,
+                             ctx->stream));
+   if (ids)
+      SPH_TRY(hipMemcpyAsync(ids, ctx->key, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_download_grid_counts(sph_hip_context* ctx, int32_t* counts)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (!counts) return SPH_HIP_ERR_INVALID;
+   const int nc = ctx->grid.ncells;
+   // counts are kept as the exclusive scan; difference them on the host
+   uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)nc + 1));
+   if (!tmp) return SPH_HIP_ERR_INVALID;
+   hipError_t e = hipMemcpyAsync(tmp, ctx->cell_start, sizeof(uint32_t) * ((size_t)nc + 1),
+                                 hipMemcpyDeviceToHost, ctx->stream);
+   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+   if (e != hipSuccess) {
+      free(tmp);
+      ctx->err = std::string("sph_hip_download_grid_counts: ") + hipGetErrorString(e);
+      return SPH_HIP_ERR_DEVICE;
+   }
+   for (int c = 0; c < nc; c++) counts[c] = (int32_t)(tmp[c + 1] - tmp[c]);
+   free(tmp);
+   return SPH_HIP_OK;
+}
+
+int sph_hip_download_neighbor_lists(sph_hip_context* ctx, uint32_t* neighbors, float* distances)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_REF) {
+      ctx->err = "sph_hip_download_neighbor_lists: REF-mode contexts only (FULL mode stores no lists)";
+      return SPH_HIP_ERR_INVALID;
+   }
+   const size_t m = (size_t)ctx->n * ctx->prm.examine_count;
+   if (neighbors)
+      SPH_TRY(hipMemcpyAsync(neighbors, ctx->nb, sizeof(uint32_t) * m, hipMemcpyDeviceToHost,
+                             ctx->stream));
+   if (distances)
+      SPH_TRY(hipMemcpyAsync(distances, ctx->nd, sizeof(float) * m, hipMemcpyDeviceToHost,
+                             ctx->stream));
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
+void* sph_hip_stream(sph_hip_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+} // extern "C"

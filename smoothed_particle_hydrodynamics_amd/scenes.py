@@ -1,0 +1,74 @@
+"""Synthetic initial conditions for the SPH step.
+
+The reference ships one scene (a rotating sphere from glibc rand(), src/sph.cpp:361-425) and
+a commented-out box/dam init (src/sph.cpp:324-358).  The generators here use a counter-based
+PRNG (SplitMix64 finaliser on the particle/component counter) so that any host — numpy here,
+C elsewhere — produces bit-identical fp32 positions from (seed, index) without libc state.
+"""
+import math
+
+import numpy as np
+
+from .lib import default_params
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def uniform01(seed, counters):
+    """24-bit uniforms in [0,1) as float32: SplitMix64 finaliser of (counter+1)*golden + seed*c."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(counters, np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = z + np.uint64(seed) * np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+def box_fill(n, lo, hi, seed=42):
+    """n points uniform in the axis-aligned box [lo, hi) (fp32), interleaved xyz."""
+    idx = np.arange(3 * n, dtype=np.uint64)
+    u = uniform01(seed, idx).reshape(n, 3)
+    lo = np.asarray(lo, np.float32)
+    ext = np.asarray(hi, np.float32) - lo
+    pos = (lo + u * ext).astype(np.float32)
+    return np.ascontiguousarray(pos.reshape(-1))
+
+
+def dam_break_h(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0):
+    """Smoothing length giving ~`neighbors` particles inside radius h in the filled column."""
+    vol = box[0] * fill[0] * box[1] * fill[1] * box[2] * fill[2]
+    number_density = n / vol
+    return (3.0 * neighbors / (4.0 * math.pi * number_density)) ** (1.0 / 3.0)
+
+
+def dam_break(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0, seed=42):
+    """Dam-break column modelled on the reference's commented-out init (src/sph.cpp:328-345):
+    uniform random points in x<0.1*Lx, y<0.75*Ly, z<Lz, at rest, unit masses.
+
+    Returns (params, pos[3n], vel[3n], mass[n]).  The voxel grid (edge 2h) covers the box; the
+    central point mass is switched off (it is the astrophysical part of the reference's
+    default scene, not of a dam-break); everything else keeps the reference's defaults.
+    """
+    h = np.float32(dam_break_h(n, box, fill, neighbors))
+    cells = [max(1, int(math.ceil(b / (2.0 * float(h))))) for b in box]
+    p = default_params(float(h), cells)
+    p.central_mass = 0.0
+    hi = [box[c] * fill[c] for c in range(3)]
+    pos = box_fill(n, (0.0, 0.0, 0.0), hi, seed)
+    vel = np.zeros(3 * n, np.float32)
+    mass = np.ones(n, np.float32)
+    return p, pos, vel, mass
+
+
+def dense_block(n, lo=(1.0, 1.0, 1.0), hi=(2.2, 2.2, 2.2), seed=7, speed=0.5):
+    """Reference default constants (h=0.1, 32^3 voxels) with n particles packed into a small
+    block, so that the shipped sampled search actually finds neighbours (its stock sphere
+    scene finds almost none).  Velocities: small uniform random."""
+    p = default_params()
+    pos = box_fill(n, lo, hi, seed)
+    vel = (box_fill(n, (-speed,) * 3, (speed,) * 3, seed + 1)).astype(np.float32)
+    mass = np.ones(n, np.float32)
+    return p, pos, vel, mass

@@ -1,0 +1,106 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports exactly what
+include/sph_hip.h declares, derives the reference's constants, and refuses to run without a
+GPU instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import to_oracle_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sph_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sph_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "sph_hip_step" in syms and "sph_hip_create" in syms and len(syms) >= 20
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    from smoothed_particle_hydrodynamics_amd.lib import PROTOTYPES
+    syms = declared_symbols()
+    for s in syms:
+        assert hasattr(hiplib, s), "libsph_hip.so does not export %s" % s
+    # the ctypes binding covers the whole header too
+    assert sorted(PROTOTYPES) == syms
+
+
+def test_param_struct_layout_matches_oracle(hiplib):
+    from oracle.oracle import OracleParams
+    from smoothed_particle_hydrodynamics_amd import SphParams
+    assert C.sizeof(OracleParams) == C.sizeof(SphParams)
+    assert [f[0] for f in OracleParams._fields_] == [f[0] for f in SphParams._fields_]
+
+
+@pytest.mark.parametrize("h,cells", [(0.1, (32, 32, 32)), (0.05, (16, 24, 8)),
+                                     (0.0051501622, (98, 98, 98)), (0.37, (5, 3, 9))])
+def test_params_default_matches_oracle(hiplib, oracle, h, cells):
+    """sph_hip_params_default == the restated constructor constants (reference
+    src/sph.cpp:46-98), byte for byte."""
+    from smoothed_particle_hydrodynamics_amd.lib import default_params
+    p = default_params(h, cells)
+    o = oracle.params_for_h(h, cells)
+    assert bytes(p) == bytes(o)
+
+
+def test_reference_default_constants(hiplib):
+    """k1 = 1.56668134e9, k2 = -14323942 for h = 0.1"""
+    from smoothed_particle_hydrodynamics_amd.lib import default_params
+    p = default_params()
+    assert np.float32(p.kernel1) == np.float32(1.56668134e9)
+    assert np.float32(p.kernel2) == np.float32(-14323942.0)
+    assert p.kernel3 == -p.kernel2
+    assert (p.cells_x, p.cells_y, p.cells_z) == (32, 32, 32)
+    assert np.float32(p.max_x) == np.float32(6.4)
+    assert p.examine_count == 32
+
+
+def test_invalid_arguments_are_reported(hiplib):
+    from smoothed_particle_hydrodynamics_amd import SphParams
+    p = SphParams()
+    assert hiplib.sph_hip_params_default(C.byref(p), -1.0, 32, 32, 32) == -1
+    assert hiplib.sph_hip_params_default(C.byref(p), 0.1, 0, 32, 32) == -1
+    ctx = C.c_void_p()
+    assert hiplib.sph_hip_create(C.byref(ctx), C.byref(p), 0, 0, 0) == -1
+    assert hiplib.sph_hip_last_error(None)  # a message, never NULL
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hiplib):
+    """Without a device the product refuses to construct; with one it constructs.  Either way
+    nothing routes to the CPU oracle."""
+    import smoothed_particle_hydrodynamics_amd as S
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        with S.SPH(1024) as s:
+            assert s.getParticleCount() == 1024
+    else:
+        with pytest.raises(S.SphHipError, match="no usable HIP device"):
+            S.SPH(1024)
+
+
+def test_missing_library_is_loud(tmp_path):
+    from smoothed_particle_hydrodynamics_amd.lib import SphHipError, load_library
+    with pytest.raises(SphHipError, match="no CPU fallback"):
+        load_library(str(tmp_path / "libsph_hip.so"))
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference oracle/ in any way."""
+    pkg = os.path.join(ROOT, "smoothed_particle_hydrodynamics_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), "%s mentions the oracle" % f
