@@ -48,3 +48,23 @@ def vec_rel(a, b):
     den = np.maximum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1))
     den[den == 0] = 1.0
     return num / den
+
+
+def energy_rtol(n):
+    """the reference accumulates N fp32 terms serially: ~sqrt(N) * 2^-24 relative, x8 margin"""
+    return 1e-6 + 8.0 * np.sqrt(float(n)) * 2.0 ** -24
+
+
+def check_energy(got, want, vel_after, mass):
+    """got: (ke, pe) from the device (double tree sum); want: the oracle's serial fp32 sums."""
+    import pytest
+    n = mass.size
+    ke, pe = got
+    assert ke == pytest.approx(want[0], rel=energy_rtol(n), abs=1e-30)
+    assert pe == pytest.approx(want[1], rel=energy_rtol(n), abs=1e-30)
+    # exact check: the same fp32 per-particle terms (reference src/sph.cpp:997-1004) summed in f64
+    v = np.asarray(vel_after, np.float32).reshape(-1, 3)
+    dot = v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2]
+    term = (np.float32(0.5) * mass.astype(np.float32)) * dot
+    ke64 = float(term[dot > 0].astype(np.float64).sum())
+    assert ke == pytest.approx(np.float32(ke64), rel=1e-6, abs=1e-30)

@@ -6,17 +6,18 @@ test_oracle_vs_reference.py).
 Bar: neighbour counts identical; density, acceleration, position, velocity bit-identical
 (the north star asks for 1e-4 relative on forces; the order-sensitive viscous sum makes
 "same neighbours in the same order" the only robust way to meet it, and then equality is
-what a correct kernel produces).  KE/PE: 1e-5 relative (different summation order).
+what a correct kernel produces).  KE/PE: the reference adds N fp32 terms serially, which alone is off by ~sqrt(N)*2^-24
+(1.6e-5 at 256k particles); tolerance energy_rtol(N).  KE is also checked to 1e-12 against a
+float64 sum of the same fp32 terms.
 """
 import numpy as np
 import pytest
 
-from helpers import to_oracle_params, vec_rel
+from helpers import check_energy, to_oracle_params, vec_rel
 
 pytestmark = pytest.mark.gpu
 
 FORCE_RTOL = 1e-4      # north star tolerance; asserted in addition to equality diagnostics
-ENERGY_RTOL = 1e-5
 
 
 def check_state(part, ref, what=""):
@@ -42,9 +43,7 @@ def run_case(oracle, p, pos, vel, mass, steps=1):
             check_state(part, ref, "step %d" % s)
             assert np.array_equal(part.mPosition, opos)
             assert np.array_equal(part.mVelocity, ovel)
-            ke, pe = sph.energy()
-            assert ke == pytest.approx(ref["ke"], rel=ENERGY_RTOL, abs=1e-30)
-            assert pe == pytest.approx(ref["pe"], rel=ENERGY_RTOL, abs=1e-30)
+            check_energy(sph.energy(), (ref["ke"], ref["pe"]), part.mVelocity, mass)
         counts = sph.getGrid()
         assert counts.sum() == mass.size
         return part.mNeighborCount.mean()
