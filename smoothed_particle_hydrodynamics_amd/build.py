@@ -20,7 +20,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 
 def library_path():
-    return os.path.join(HERE, "libsph_hip.so")
+    # SPH_HIP_LIBRARY points experiments at a diagnostic build; the product uses the in-tree one
+    return os.environ.get("SPH_HIP_LIBRARY") or os.path.join(HERE, "libsph_hip.so")
 
 
 def _stale(out):

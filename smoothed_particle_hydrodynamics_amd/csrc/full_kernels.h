@@ -37,13 +37,17 @@ __device__ __forceinline__ void row_ranges(const CellGrid& g, const uint32_t* __
    }
 }
 
-// ---- density (v1: one thread per particle, candidates read through L1/L2) -----------------
+// ---- density, untiled: one thread per particle, candidates read through L1/L2.  Used for
+// workgroups whose LDS tile would overflow (full_tiled.h) and as an independent cross-check.
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
 k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start, int n,
                CellGrid g, PairConsts k, float* __restrict__ rho, float2* __restrict__ aux,
-               int32_t* __restrict__ ncount)
+               int32_t* __restrict__ ncount, const int* __restrict__ tile_total, int tile_cap)
 {
+   // as the fallback of the tiled kernel: run only the workgroups whose tile overflowed
+   // (tile_total points at TileDesc::total of workgroup 0, stride 20 ints)
+   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= n) return;
    const float4 pi = posm[p];
@@ -74,14 +78,15 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
    ncount[p] = count;
 }
 
-// ---- acceleration (v1) -------------------------------------------------------------------------
+// ---- acceleration, untiled ------------------------------------------------------------------------
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
 k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
              const float* __restrict__ rho, const float2* __restrict__ aux,
              const uint32_t* __restrict__ cell_start, int n, CellGrid g, PairConsts k,
-             float4* __restrict__ acc)
+             float4* __restrict__ acc, const int* __restrict__ tile_total, int tile_cap)
 {
+   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= n) return;
    const float4 pi = posm[p];

@@ -77,6 +77,9 @@ struct sph_hip_context {
    float2* aux = nullptr; // per particle {p_j * rhojInv^2, (rhojInv * m_j) * k3}
    float4* acc = nullptr; // {ax, ay, az, unused}
    int32_t* ncount = nullptr;
+   struct TileDesc* tile_desc = nullptr; // per 256-particle workgroup: LDS tile layout
+   int uniform_mass = 0;           // every resident particle has bit-identical mass
+   int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
 
    // REF-mode lists
    int32_t* vox = nullptr; // 3 ints per particle

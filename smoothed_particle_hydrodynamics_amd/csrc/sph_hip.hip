@@ -10,6 +10,7 @@
 #include "cell_build.h"
 #include "common_kernels.h"
 #include "full_kernels.h"
+#include "full_tiled.h"
 #include "ref_kernels.h"
 
 #ifndef M_PI
@@ -64,7 +65,7 @@ void free_all(sph_hip_context* ctx)
    }
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
                    ctx->scan_part, ctx->rho, ctx->aux, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
-                   ctx->nd, ctx->epart, ctx->stats, ctx->stage};
+                   ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc};
    for (void* q : ptrs)
       if (q) (void)hipFree(q);
    if (ctx->ev) {
@@ -136,6 +137,21 @@ int launch_find_neighbors(sph_hip_context* ctx)
    return SPH_HIP_OK;
 }
 
+template <int PASS>
+void launch_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
+{
+#define SPH_TILED(U, M)                                                                          \
+   hipLaunchKernelGGL((k_full_tiled<U, M, PASS>), dim3(blocks), dim3(TILE_THREADS), 0,           \
+                      ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux, \
+                      ctx->cell_start, ctx->n, ctx->grid, k, ctx->rho, ctx->aux, ctx->ncount,    \
+                      ctx->acc, ctx->tile_desc)
+   if (unit && ctx->uniform_mass) SPH_TILED(true, true);
+   else if (unit) SPH_TILED(true, false);
+   else if (ctx->uniform_mass) SPH_TILED(false, true);
+   else SPH_TILED(false, false);
+#undef SPH_TILED
+}
+
 int launch_density(sph_hip_context* ctx)
 {
    const int n = ctx->n;
@@ -145,14 +161,29 @@ int launch_density(sph_hip_context* ctx)
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_ref_density, dim3(blocks), dim3(256), 0, ctx->stream, ctx->posm[0],
                          ctx->nb, ctx->nd, ctx->ncount, n, ctx->prm.examine_count, k, ctx->rho);
-   } else if (unit_scale(ctx->prm)) {
-      hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho, ctx->aux,
-                         ctx->ncount);
    } else {
-      hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho, ctx->aux,
-                         ctx->ncount);
+      const bool unit = unit_scale(ctx->prm);
+      const int* flags = nullptr;
+      if (ctx->use_tiled) {
+         static_assert(sizeof(TileDesc) == 20 * sizeof(int), "fallback kernels index TileDesc::total");
+         flags = &ctx->tile_desc->total;
+         hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, blocks,
+                            ctx->tile_desc);
+         launch_tiled<0>(ctx, unit, blocks, k);
+      }
+#if defined(SPH_ABLATE) && SPH_ABLATE == 6
+      if (false) {}
+      else
+#endif
+      if (unit)
+         hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho,
+                            ctx->aux, ctx->ncount, flags, TILE_CAP);
+      else
+         hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho,
+                            ctx->aux, ctx->ncount, flags, TILE_CAP);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -168,14 +199,26 @@ int launch_accel(sph_hip_context* ctx)
       hipLaunchKernelGGL(k_ref_accel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->posm[0],
                          ctx->velp[0], ctx->rho, ctx->nb, ctx->nd, ctx->ncount, n,
                          ctx->prm.examine_count, k, ctx->acc);
-   } else if (unit_scale(ctx->prm)) {
-      hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
-                         ctx->cell_start, n, ctx->grid, k, ctx->acc);
    } else {
-      hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
-                         ctx->cell_start, n, ctx->grid, k, ctx->acc);
+      const bool unit = unit_scale(ctx->prm);
+      const int* flags = nullptr;
+      if (ctx->use_tiled) {
+         // descriptors written by launch_density for the same cell-sorted state
+         flags = &ctx->tile_desc->total;
+         launch_tiled<1>(ctx, unit, blocks, k);
+      }
+#if defined(SPH_ABLATE) && SPH_ABLATE == 6
+      if (false) {}
+      else
+#endif
+      if (unit)
+         hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
+                            ctx->cell_start, n, ctx->grid, k, ctx->acc, flags, TILE_CAP);
+      else
+         hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
+                            ctx->cell_start, n, ctx->grid, k, ctx->acc, flags, TILE_CAP);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -352,6 +395,8 @@ int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capa
    CREATE_TRY(hipMemsetAsync(ctx->ncount, 0, cap * sizeof(int32_t), ctx->stream));
    if (mode == SPH_HIP_MODE_FULL) {
       CREATE_TRY(dev_alloc(&ctx->aux, cap));
+      CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
+      if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
    } else {
       CREATE_TRY(dev_alloc(&ctx->order, cap));
       CREATE_TRY(dev_alloc(&ctx->vox, cap * 3));
@@ -420,6 +465,14 @@ int sph_hip_upload(sph_hip_context* ctx, int n, const float* pos, const float* v
    ctx->n = n;
    ctx->n_owned = n;
    ctx->cur = 0;
+   // the reference gives every particle the same mass (src/sph.cpp:105-108); when the upload
+   // does too, the tiled kernels skip the per-neighbour mass gather (bit-identical results)
+   ctx->uniform_mass = 1;
+   for (int i = 1; i < n; i++)
+      if (memcmp(&mass[i], &mass[0], sizeof(float)) != 0) {
+         ctx->uniform_mass = 0;
+         break;
+      }
    ctx->ev_steps = 0;
    if (n == 0) return SPH_HIP_OK;
    float* spos = ctx->stage;
