@@ -216,6 +216,7 @@ class Reference:
                                                    p.cfl_limit, p.grav_const, p.central_mass)],
                           pos0)
         L.ref_set_examine_count(p.examine_count)
+        L.ref_set_scale(C.c_float(p.sim_scale), C.c_float(p.sim_scale_inv))
         L.ref_resize(n)
 
     def constants(self):

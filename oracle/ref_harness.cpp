@@ -108,6 +108,13 @@ void ref_set_h(float h, float h2, float hscaled, float hscaled2, float hscaled6,
    s->mSoftening = softening;
 }
 
+// mSimulationScale / mSimulationScaleInverse (reference src/sph.cpp:48-49, fixed at 1 there)
+void ref_set_scale(float scale, float scale_inv)
+{
+   S()->mSimulationScale = scale;
+   S()->mSimulationScaleInverse = scale_inv;
+}
+
 void ref_set_physics(float rho0, float stiffness, float viscosity, float dt, float cfl,
                      float grav_const, float central_mass, const float* central_pos)
 {
