@@ -20,6 +20,7 @@
 #ifndef SPH_HIP_H
 #define SPH_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -174,10 +175,56 @@ int sph_hip_download_grid_counts(sph_hip_context* ctx, int32_t* counts);
  * (reference src/sph.cpp:112-113). */
 int sph_hip_download_neighbor_lists(sph_hip_context* ctx, uint32_t* neighbors, float* distances);
 
+/* ---- multi-GPU: 1-D slab decomposition of the FULL-mode cell grid ------------------------- *
+ *
+ * No counterpart in the reference (one process, one thread).  One context per GPU owns the
+ * global z-planes [plane_lo, plane_hi) of the FULL grid and additionally holds
+ * SPH_HIP_SLAB_HALO (= 2) ghost planes on each side: with two planes the densities of the
+ * ghosts next to the slab are recomputed locally from complete neighbourhoods, in the same
+ * canonical order (cell id, particle id) as on their owner, so ONE exchange per step is enough
+ * and results do not depend on the number of slabs.
+ *
+ * Per step, on every rank:
+ *     sph_hip_slab_pack   -> two device messages (left / right neighbour)
+ *     <transport>            RCCL send/recv over xGMI (torch.distributed), or a device copy
+ *     sph_hip_slab_unpack <- the two messages received
+ *     sph_hip_step
+ * A message is sph_hip_slab_message_bytes(capacity) bytes of DEVICE memory owned by the
+ * caller: 8 int32 header words (word 0 = record count) + 32-byte records
+ * {x,y,z,m,vx,vy,vz,id}.  Every step a slab re-sends each owned particle that lies within the
+ * halo width of (or beyond) a neighbour's border: the receiver treats records inside its own
+ * planes as migrants (now owned) and the rest as ghosts; ghosts are dropped and re-sent every
+ * step.  All counts stay on the device — none of these calls synchronises with the host.
+ * sph_hip_create() is the special case plane_lo = 0, plane_hi = all planes, no neighbours. */
+#define SPH_HIP_SLAB_HALO 2
+
+int sph_hip_create_slab(sph_hip_context** out, const sph_hip_params* params, int capacity,
+                        int device, int plane_lo, int plane_hi);
+/* Owned particles of this slab with their GLOBAL persistent ids (the canonical order inside
+ * a cell is by id).  all_masses_equal: non-zero iff every particle of the WHOLE system has
+ * the same mass (enables the same fast path as sph_hip_upload detects by itself). */
+int sph_hip_slab_upload(sph_hip_context* ctx, int n, const float* pos, const float* vel,
+                        const float* mass, const uint32_t* ids, int all_masses_equal);
+/* Owned particles in cell-sorted order: *rows receives their number (synchronises). */
+int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uint32_t* ids,
+                          float* pos, float* vel, float* density, float* acc,
+                          int32_t* neighbor_count);
+size_t sph_hip_slab_message_bytes(int capacity_records);
+/* NULL for a side without neighbour.  Call after sph_hip_step()/upload, before the transport. */
+int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_device,
+                      int capacity_records);
+int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const void* right_device,
+                        int capacity_records);
+/* Diagnostics (synchronises): live entries, owned particles, error bits (1: a particle left
+ * the slab and its halo in one step, 2: a message overflowed, 4: context capacity exceeded). */
+int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors);
+
 /* ---- streams ----------------------------------------------------------------------------- */
 
-/* Opaque device handles for callers that overlap communication with compute: the HIP
- * stream all of ctx's kernels run on. */
+/* Run all of ctx's work on the caller's HIP stream (e.g. the stream torch.distributed orders
+ * its RCCL calls against); NULL returns to the context's own stream. */
+int sph_hip_set_stream(sph_hip_context* ctx, void* hip_stream);
+/* The HIP stream all of ctx's kernels currently run on. */
 void* sph_hip_stream(sph_hip_context* ctx);
 
 #ifdef __cplusplus

@@ -22,18 +22,23 @@
 // the others take base + their rank in the run.
 template <bool WRITE_VOX>
 __global__ void __launch_bounds__(256)
-k_hash_count(const float4* __restrict__ posm, int n, CellGrid g, uint32_t* __restrict__ key,
+k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
+             int32_t* __restrict__ meta, CellGrid g, uint32_t* __restrict__ key,
              uint32_t* __restrict__ slot, uint32_t* __restrict__ cell_count,
              int32_t* __restrict__ vox)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    const int lane = threadIdx.x & (SPH_WAVE - 1);
-   const bool live = i < n;
+   const bool live = i < meta[META_N_IN];
    uint32_t c = 0xffffffffu;
    if (live) {
       const float4 p = posm[i];
       int cx, cy, cz;
       c = cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+      if (__float_as_uint(velp[i].w) == SPH_DEAD_ID)
+         c = (uint32_t)g.ncells;  // dropped ghost / departed particle
+      else if (c == (uint32_t)g.ncells)
+         atomicOr(&meta[META_ERRORS], 1);  // a live particle outside the slab and its halo
       key[i] = c;
       if (WRITE_VOX) {
          vox[3 * i + 0] = cx;
@@ -180,19 +185,21 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
 // ---- 3. scatter -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
-          const uint32_t* __restrict__ cell_start, int n, uint32_t* __restrict__ perm)
+          const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
+          uint32_t* __restrict__ perm)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i < n) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
+   if (i < meta[META_N_IN]) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
 }
 
 // ---- 4a. REF: ascending-index order inside each cell ---------------------------------------
 __global__ void __launch_bounds__(256)
 k_rank_order(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
-             const uint32_t* __restrict__ cell_start, int n, uint32_t* __restrict__ order)
+             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
+             uint32_t* __restrict__ order)
 {
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= n) return;
+   if (p >= meta[META_N_IN]) return;
    const uint32_t i = perm[p];
    const uint32_t c = key[i];
    const uint32_t s = cell_start[c], e = cell_start[c + 1];
@@ -204,14 +211,15 @@ k_rank_order(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key
 // ---- 4b. FULL: gather the state into cell-sorted order, ascending persistent id in a cell ----
 __global__ void __launch_bounds__(256)
 k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
-              const uint32_t* __restrict__ cell_start, int n, const float4* __restrict__ posm_in,
-              const float4* __restrict__ velp_in, float4* __restrict__ posm_out,
-              float4* __restrict__ velp_out)
+              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, int trash,
+              const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
+              float4* __restrict__ posm_out, float4* __restrict__ velp_out)
 {
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= n) return;
+   if (p >= meta[META_N_IN]) return;
    const uint32_t i = perm[p];
    const uint32_t c = key[i];
+   if (c == (uint32_t)trash) return;  // dead entries are dropped: the live set is compacted
    const uint32_t s = cell_start[c], e = cell_start[c + 1];
    const float4 v = velp_in[i];
    const uint32_t id = __float_as_uint(v.w);
@@ -222,4 +230,19 @@ k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ ke
    }
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;
+}
+
+// ---- 5. sorted ranges of a slab ----------------------------------------------------------------
+// After the scan: how many entries are live, which sorted range is owned (planes [lo, hi)) and
+// which range needs densities (one more plane on each side).  Planes are LOCAL indices.
+__global__ void k_slab_ranges(const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
+                              int cells_per_plane, int ncells, int own_lo, int own_hi, int sum_lo,
+                              int sum_hi)
+{
+   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+   meta[META_N_LIVE] = (int)cell_start[ncells];
+   meta[META_OWN_BEGIN] = (int)cell_start[own_lo * cells_per_plane];
+   meta[META_OWN_END] = (int)cell_start[own_hi * cells_per_plane];
+   meta[META_SUM_BEGIN] = (int)cell_start[sum_lo * cells_per_plane];
+   meta[META_SUM_END] = (int)cell_start[sum_hi * cells_per_plane];
 }

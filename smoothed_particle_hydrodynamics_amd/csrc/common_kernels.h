@@ -13,11 +13,12 @@
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(RED_THREADS)
 k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* __restrict__ acc,
-            int n, PairConsts k, double* __restrict__ epart)
+            const int32_t* __restrict__ meta, PairConsts k, double* __restrict__ epart)
 {
-   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   // owned particles only: ghosts are integrated by the slab that owns them
+   const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
    double ke = 0.0, pe = 0.0;
-   if (p < n) {
+   if (p < meta[META_OWN_END]) {
       float4 x = posm[p];
       float4 v = velp[p];
       const float4 a = acc[p];
@@ -111,27 +112,33 @@ k_energy_total(const double* __restrict__ epart, int nblocks, double* __restrict
 // stage holds the reference's arrays back to back: pos[3n] vel[3n] mass[n]
 __global__ void __launch_bounds__(256)
 k_import(const float* __restrict__ pos, const float* __restrict__ vel,
-         const float* __restrict__ mass, int n, float4* __restrict__ posm,
-         float4* __restrict__ velp)
+         const float* __restrict__ mass, const uint32_t* __restrict__ ids, int n,
+         float4* __restrict__ posm, float4* __restrict__ velp)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
+   const uint32_t id = ids ? ids[i] : (uint32_t)i;
    posm[i] = make_float4(pos[3 * i + 0], pos[3 * i + 1], pos[3 * i + 2], mass[i]);
-   velp[i] = make_float4(vel[3 * i + 0], vel[3 * i + 1], vel[3 * i + 2], __uint_as_float((uint32_t)i));
+   velp[i] = make_float4(vel[3 * i + 0], vel[3 * i + 1], vel[3 * i + 2], __uint_as_float(id));
 }
 
 // scatter by persistent id into pos[3n] vel[3n] rho[n] acc[3n] ncount[n] (any may be null)
+// `compact`: write row (p - own_begin) instead of row id, and the ids to oid (slab download)
 __global__ void __launch_bounds__(256)
 k_export(const float4* __restrict__ posm, const float4* __restrict__ velp,
          const float* __restrict__ rho, const float4* __restrict__ acc,
-         const int32_t* __restrict__ ncount, int n, float* __restrict__ pos,
-         float* __restrict__ vel, float* __restrict__ orho, float* __restrict__ oacc,
-         int32_t* __restrict__ ocount)
+         const int32_t* __restrict__ ncount, const int32_t* __restrict__ meta, int compact,
+         float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ orho,
+         float* __restrict__ oacc, int32_t* __restrict__ ocount, uint32_t* __restrict__ oid)
 {
-   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= n) return;
+   const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_OWN_END]) return;
    const float4 v = velp[p];
-   const uint32_t id = __float_as_uint(v.w);
+   uint32_t id = __float_as_uint(v.w);
+   if (compact) {
+      if (oid) oid[p - meta[META_OWN_BEGIN]] = id;
+      id = (uint32_t)(p - meta[META_OWN_BEGIN]);
+   }
    if (pos) {
       const float4 x = posm[p];
       pos[3 * id + 0] = x.x;
@@ -156,11 +163,13 @@ k_export(const float4* __restrict__ posm, const float4* __restrict__ velp,
 // ---- neighbour statistics (reference src/sph.cpp:204-232) -----------------------------------------
 // out: [0] = sum low 32, [1] = sum high 32 (as one 64-bit add), [2] = max, [3] = min (from 34)
 __global__ void __launch_bounds__(RED_THREADS)
-k_neighbor_stats(const int32_t* __restrict__ ncount, int n, int32_t* __restrict__ out)
+k_neighbor_stats(const int32_t* __restrict__ ncount, const int32_t* __restrict__ meta,
+                 int32_t* __restrict__ out)
 {
    long long sum = 0;
    int mx = -1, mn = 34;
-   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+   const int begin = meta[META_OWN_BEGIN], end = meta[META_OWN_END];
+   for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
       const int c = ncount[i];
       sum += c;
       mx = c > mx ? c : mx;

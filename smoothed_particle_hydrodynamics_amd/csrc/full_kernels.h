@@ -41,15 +41,16 @@ __device__ __forceinline__ void row_ranges(const CellGrid& g, const uint32_t* __
 // workgroups whose LDS tile would overflow (full_tiled.h) and as an independent cross-check.
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
-k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start, int n,
-               CellGrid g, PairConsts k, float* __restrict__ rho, float2* __restrict__ aux,
-               int32_t* __restrict__ ncount, const int* __restrict__ tile_total, int tile_cap)
+k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
+               const int32_t* __restrict__ meta, CellGrid g, PairConsts k, float* __restrict__ rho,
+               float2* __restrict__ aux, int32_t* __restrict__ ncount,
+               const int* __restrict__ tile_total, int tile_cap)
 {
    // as the fallback of the tiled kernel: run only the workgroups whose tile overflowed
    // (tile_total points at TileDesc::total of workgroup 0, stride 20 ints)
    if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
-   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= n) return;
+   const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_SUM_END]) return;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
@@ -83,12 +84,13 @@ template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
 k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
              const float* __restrict__ rho, const float2* __restrict__ aux,
-             const uint32_t* __restrict__ cell_start, int n, CellGrid g, PairConsts k,
-             float4* __restrict__ acc, const int* __restrict__ tile_total, int tile_cap)
+             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
+             PairConsts k, float4* __restrict__ acc, const int* __restrict__ tile_total,
+             int tile_cap)
 {
    if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
-   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= n) return;
+   const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_OWN_END]) return;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);

@@ -59,13 +59,16 @@ struct TileLds {
 // One thread per workgroup-to-be: the 9 row segments (cells c_first-1 .. c_last+1 of every
 // (dz,dy) row, as linear cell-id ranges) of the 256 particles starting at tile*256.
 __global__ void __launch_bounds__(256)
-k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start, int n,
-            CellGrid g, int ntiles, TileDesc* __restrict__ desc)
+k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
+            const int32_t* __restrict__ meta, int range, CellGrid g, int ntiles,
+            TileDesc* __restrict__ desc)
 {
    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
    if (tile >= ntiles) return;
-   const int p0 = tile * TILE_THREADS;
-   const int plast = min(p0 + TILE_THREADS - 1, n - 1);
+   const int begin = meta[range], end = meta[range + 1];
+   const int p0 = begin + tile * TILE_THREADS;
+   if (p0 >= end) return;
+   const int plast = min(p0 + TILE_THREADS - 1, end - 1);
    const float4 a = posm[p0], b = posm[plast];
    int cx, cy, cz;
    const int c_first = (int)cell_of(g, a.x, a.y, a.z, cx, cy, cz);
@@ -258,17 +261,22 @@ template <bool UNIT_SCALE, bool UNIFORM_MASS, int PASS>
 __global__ void __launch_bounds__(TILE_THREADS, 3)
 k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
              const float* __restrict__ rho_in, const float2* __restrict__ aux_in,
-             const uint32_t* __restrict__ cell_start, int n, CellGrid g, PairConsts k,
-             float* __restrict__ rho_out, float2* __restrict__ aux_out,
+             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
+             PairConsts k, float* __restrict__ rho_out, float2* __restrict__ aux_out,
              int32_t* __restrict__ ncount, float4* __restrict__ acc,
              const TileDesc* __restrict__ desc)
 {
    __shared__ __attribute__((aligned(16))) TileLds L;
 
+   // density runs over planes [lo-1, hi+1) (the owned particles' neighbours need it), the
+   // acceleration over the owned planes only; both are contiguous ranges of the sorted state
+   const int begin = meta[PASS == 0 ? META_SUM_BEGIN : META_OWN_BEGIN];
+   const int end = meta[PASS == 0 ? META_SUM_END : META_OWN_END];
    const int tid = threadIdx.x;
-   const int p0 = blockIdx.x * TILE_THREADS;
+   const int p0 = begin + blockIdx.x * TILE_THREADS;
+   if (p0 >= end) return;
    const int p = p0 + tid;
-   const bool live = p < n;
+   const bool live = p < end;
    tile_load(posm, desc, L);
    if (L.desc.total > TILE_CAP) return;  // tile does not fit: the untiled kernel redoes this workgroup
 

@@ -24,10 +24,26 @@
 
 // Grid description handed to kernels by value.
 struct CellGrid {
-   int nx, ny, nz;
-   float inv;  // cells per unit length
-   int ncells;
+   int nx, ny, nz;  // cells held by this context (nz = local planes for a slab)
+   float inv;       // cells per unit length
+   int ncells;      // nx*ny*nz; cell id `ncells` is the trash cell (dead / out-of-slab entries)
+   int z0;          // global z-plane of local plane 0
+   int nz_global;   // planes of the whole grid (positions are clamped against this)
 };
+
+// Device-side counts and ranges of a context (int32 each); kernels read them so that a step
+// never needs a host round trip.
+enum {
+   META_N_IN = 0,      // entries in the input arrays of the next cell build
+   META_N_LIVE = 1,    // entries in real cells after the build (sorted order [0, n_live))
+   META_OWN_BEGIN = 2, // sorted range of owned particles (planes [lo, hi))
+   META_OWN_END = 3,
+   META_SUM_BEGIN = 4, // sorted range whose density is needed (planes [lo-1, hi+1))
+   META_SUM_END = 5,
+   META_ERRORS = 6,    // bit 0: entry outside slab+halo, bit 1: message overflow, bit 2: capacity
+   META_COUNT = 8
+};
+#define SPH_DEAD_ID 0xffffffffu
 
 // Constants of the per-pair arithmetic, by value in kernarg (scalar registers).
 struct PairConsts {
@@ -44,9 +60,13 @@ struct sph_hip_context {
    int mode = 0;
    int device = 0;
    int capacity = 0;
-   int n = 0;       // particles resident (owned + ghosts)
-   int n_owned = 0; // particles integrated / downloaded
-   hipStream_t stream = nullptr;
+   int n = 0;       // host upper bound of resident entries (owned + ghosts + dead)
+   int n_owned = 0; // owned particles at the last upload / count query
+   int32_t* meta = nullptr; // META_* (device)
+   // slab (FULL mode): owned global z-planes [plane_lo, plane_hi), halo planes on each side
+   int plane_lo = 0, plane_hi = 0, halo = 0;
+   hipStream_t stream = nullptr;     // the stream every launch goes to
+   hipStream_t own_stream = nullptr; // created with the context; `stream` may be redirected
    // per-phase event ring: EV_RING steps x 7 events; `ev_steps` counts timed steps since the
    // last reset (phase totals cover the last min(ev_steps, EV_RING) of them)
    hipEvent_t* ev = nullptr;
@@ -113,12 +133,15 @@ __device__ __forceinline__ int cell_coord(float x, float inv, int ncell)
    return c;
 }
 
+// Cell of a position.  cz is the LOCAL plane (global plane - g.z0); a position whose plane lies
+// outside the planes this context holds gets the trash cell id g.ncells.
 __device__ __forceinline__ uint32_t cell_of(const CellGrid& g, float x, float y, float z, int& cx,
                                            int& cy, int& cz)
 {
    cx = cell_coord(x, g.inv, g.nx);
    cy = cell_coord(y, g.inv, g.ny);
-   cz = cell_coord(z, g.inv, g.nz);
+   cz = cell_coord(z, g.inv, g.nz_global) - g.z0;
+   if (cz < 0 || cz >= g.nz) return (uint32_t)g.ncells;
    return (uint32_t)((cz * g.ny + cy) * g.nx + cx);
 }
 

@@ -12,6 +12,7 @@
 #include "full_kernels.h"
 #include "full_tiled.h"
 #include "ref_kernels.h"
+#include "slab_kernels.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -65,7 +66,7 @@ void free_all(sph_hip_context* ctx)
    }
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
                    ctx->scan_part, ctx->rho, ctx->aux, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
-                   ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc};
+                   ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta};
    for (void* q : ptrs)
       if (q) (void)hipFree(q);
    if (ctx->ev) {
@@ -73,7 +74,7 @@ void free_all(sph_hip_context* ctx)
          if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
       delete[] ctx->ev;
    }
-   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 }
 
 int check_ctx(sph_hip_context* ctx)
@@ -91,35 +92,48 @@ int check_ctx(sph_hip_context* ctx)
 
 int launch_cell_build(sph_hip_context* ctx)
 {
-   const int n = ctx->n;
+   const int n = ctx->n;  // host upper bound of entries; the exact count is meta[META_N_IN]
    if (n == 0) return SPH_HIP_OK;
    const int blocks = div_up(n, 256);
    const CellGrid g = ctx->grid;
    hipStream_t st = ctx->stream;
-   const float4* posm = ctx->posm[ctx->cur];
+   const int cur = ctx->cur;
    if (ctx->mode == SPH_HIP_MODE_REF)
-      hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, posm, n, g, ctx->key,
-                         ctx->slot, ctx->cell_count, ctx->vox);
+      hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
+                         ctx->vox);
    else
-      hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, posm, n, g, ctx->key,
-                         ctx->slot, ctx->cell_count, (int32_t*)nullptr);
+      hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
+                         (int32_t*)nullptr);
+   // the scan covers the real cells plus the trash cell, so cell_start[ncells] = live entries
    const int tiles = ctx->scan_tiles;
+   const int ncells_scan = g.ncells + 1;
    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
-                      g.ncells, ctx->scan_part);
+                      ncells_scan, ctx->scan_part);
    hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(SCAN_THREADS), 0, st, ctx->scan_part, tiles);
    hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
-                      g.ncells, ctx->scan_part, ctx->cell_start);
+                      ncells_scan, ctx->scan_part, ctx->cell_start);
+   // sorted ranges: owned planes [lo, hi), density planes one wider (clipped to what is held)
+   const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
+   const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
+   const int sum_hi = own_hi + 1 > g.nz ? g.nz : own_hi + 1;
+   hipLaunchKernelGGL(k_slab_ranges, dim3(1), dim3(1), 0, st, ctx->cell_start, ctx->meta,
+                      g.nx * g.ny, g.ncells, own_lo, own_hi, sum_lo, sum_hi);
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
-                      ctx->cell_start, n, ctx->perm);
+                      ctx->cell_start, ctx->meta, ctx->perm);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
-                         ctx->cell_start, n, ctx->order);
+                         ctx->cell_start, ctx->meta, ctx->order);
    } else {
-      const int nxt = ctx->cur ^ 1;
+      const int nxt = cur ^ 1;
       hipLaunchKernelGGL(k_rank_gather, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
-                         ctx->cell_start, n, ctx->posm[ctx->cur], ctx->velp[ctx->cur],
+                         ctx->cell_start, ctx->meta, g.ncells, ctx->posm[cur], ctx->velp[cur],
                          ctx->posm[nxt], ctx->velp[nxt]);
       ctx->cur = nxt;
+      // the live set is now compacted at the front of the new buffers
+      hipLaunchKernelGGL(k_slab_set_n_in, dim3(1), dim3(1), 0, st, ctx->meta,
+                         (const SlabMsg*)nullptr, (const SlabMsg*)nullptr, ctx->capacity, 0, 0);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -143,7 +157,7 @@ void launch_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts&
 #define SPH_TILED(U, M)                                                                          \
    hipLaunchKernelGGL((k_full_tiled<U, M, PASS>), dim3(blocks), dim3(TILE_THREADS), 0,           \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux, \
-                      ctx->cell_start, ctx->n, ctx->grid, k, ctx->rho, ctx->aux, ctx->ncount,    \
+                      ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->aux, ctx->ncount, \
                       ctx->acc, ctx->tile_desc)
    if (unit && ctx->uniform_mass) SPH_TILED(true, true);
    else if (unit) SPH_TILED(true, false);
@@ -168,8 +182,8 @@ int launch_density(sph_hip_context* ctx)
          static_assert(sizeof(TileDesc) == 20 * sizeof(int), "fallback kernels index TileDesc::total");
          flags = &ctx->tile_desc->total;
          hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, blocks,
-                            ctx->tile_desc);
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
+                            ctx->grid, blocks, ctx->tile_desc);
          launch_tiled<0>(ctx, unit, blocks, k);
       }
 #if defined(SPH_ABLATE) && SPH_ABLATE == 6
@@ -178,12 +192,12 @@ int launch_density(sph_hip_context* ctx)
 #endif
       if (unit)
          hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho,
-                            ctx->aux, ctx->ncount, flags, TILE_CAP);
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, ctx->grid, k,
+                            ctx->rho, ctx->aux, ctx->ncount, flags, TILE_CAP);
       else
          hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, n, ctx->grid, k, ctx->rho,
-                            ctx->aux, ctx->ncount, flags, TILE_CAP);
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, ctx->grid, k,
+                            ctx->rho, ctx->aux, ctx->ncount, flags, TILE_CAP);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -203,8 +217,11 @@ int launch_accel(sph_hip_context* ctx)
       const bool unit = unit_scale(ctx->prm);
       const int* flags = nullptr;
       if (ctx->use_tiled) {
-         // descriptors written by launch_density for the same cell-sorted state
+         // workgroups now tile the OWNED range (the density pass tiled a wider one)
          flags = &ctx->tile_desc->total;
+         hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_OWN_BEGIN,
+                            ctx->grid, blocks, ctx->tile_desc);
          launch_tiled<1>(ctx, unit, blocks, k);
       }
 #if defined(SPH_ABLATE) && SPH_ABLATE == 6
@@ -214,11 +231,11 @@ int launch_accel(sph_hip_context* ctx)
       if (unit)
          hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
-                            ctx->cell_start, n, ctx->grid, k, ctx->acc, flags, TILE_CAP);
+                            ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc, flags, TILE_CAP);
       else
          hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
-                            ctx->cell_start, n, ctx->grid, k, ctx->acc, flags, TILE_CAP);
+                            ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc, flags, TILE_CAP);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -226,16 +243,18 @@ int launch_accel(sph_hip_context* ctx)
 
 int launch_integrate(sph_hip_context* ctx)
 {
-   const int n = ctx->n_owned;
+   const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
    const PairConsts k = pair_consts(ctx->prm);
    const int blocks = div_up(n, RED_THREADS);
    if (unit_scale(ctx->prm))
       hipLaunchKernelGGL(k_integrate<true>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, n, k, ctx->epart + 2);
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k,
+                         ctx->epart + 2);
    else
       hipLaunchKernelGGL(k_integrate<false>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, n, k, ctx->epart + 2);
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k,
+                         ctx->epart + 2);
    hipLaunchKernelGGL(k_energy_total, dim3(1), dim3(RED_THREADS), 0, ctx->stream, ctx->epart + 2,
                       blocks, ctx->epart);
    SPH_TRY(hipGetLastError());
@@ -316,8 +335,8 @@ int sph_hip_params_default(sph_hip_params* p, float h, int cells_x, int cells_y,
    return SPH_HIP_OK;
 }
 
-int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
-                   int device)
+static int create_impl(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
+                       int device, int plane_lo, int plane_hi, int halo)
 {
    if (!out || !params || capacity < 1 || (mode != SPH_HIP_MODE_REF && mode != SPH_HIP_MODE_FULL)) {
       g_create_error = "sph_hip_create: invalid argument";
@@ -340,20 +359,34 @@ int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capa
 
    CellGrid& g = ctx->grid;
    if (mode == SPH_HIP_MODE_REF) {
-      g.nx = params->cells_x; g.ny = params->cells_y; g.nz = params->cells_z;
+      g.nx = params->cells_x; g.ny = params->cells_y; g.nz_global = params->cells_z;
       g.inv = params->htimes2inv;
    } else {
-      g.nx = params->full_cells_x; g.ny = params->full_cells_y; g.nz = params->full_cells_z;
+      g.nx = params->full_cells_x; g.ny = params->full_cells_y; g.nz_global = params->full_cells_z;
       g.inv = params->full_cell_inv;
    }
+   if (plane_hi < 0) plane_hi = g.nz_global;  // whole grid
+   if (g.nx < 1 || g.ny < 1 || g.nz_global < 1 || plane_lo < 0 || plane_hi > g.nz_global ||
+       plane_lo >= plane_hi || (mode == SPH_HIP_MODE_REF && (plane_lo != 0 || plane_hi != g.nz_global))) {
+      g_create_error = "sph_hip_create: bad grid shape or slab range";
+      delete ctx;
+      return SPH_HIP_ERR_INVALID;
+   }
+   ctx->plane_lo = plane_lo;
+   ctx->plane_hi = plane_hi;
+   ctx->halo = halo;
+   // planes held: the owned ones plus `halo` ghost planes on each side, clipped to the grid
+   g.z0 = plane_lo - halo < 0 ? 0 : plane_lo - halo;
+   const int z1 = plane_hi + halo > g.nz_global ? g.nz_global : plane_hi + halo;
+   g.nz = z1 - g.z0;
    const long long ncells = (long long)g.nx * g.ny * g.nz;
-   if (g.nx < 1 || g.ny < 1 || g.nz < 1 || ncells > 0x7fff0000ll) {
-      g_create_error = "sph_hip_create: bad grid shape";
+   if (ncells > 0x7fff0000ll) {
+      g_create_error = "sph_hip_create: grid too large";
       delete ctx;
       return SPH_HIP_ERR_INVALID;
    }
    g.ncells = (int)ncells;
-   ctx->scan_tiles = div_up(g.ncells, SCAN_TILE);
+   ctx->scan_tiles = div_up(g.ncells + 1, SCAN_TILE);
    ctx->eblocks = div_up(capacity, RED_THREADS);
 
    auto fail = [&](const char* what, hipError_t err) {
@@ -369,7 +402,8 @@ int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capa
    } while (0)
 
    CREATE_TRY(hipSetDevice(device));
-   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+   CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+   ctx->stream = ctx->own_stream;
    ctx->ev = new hipEvent_t[EV_RING * 7]();
    for (int k = 0; k < EV_RING * 7; k++) CREATE_TRY(hipEventCreate(&ctx->ev[k]));
    const size_t cap = (size_t)capacity;
@@ -387,12 +421,15 @@ int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capa
    CREATE_TRY(dev_alloc(&ctx->cell_start, cells_padded));
    CREATE_TRY(dev_alloc(&ctx->scan_part, (size_t)ctx->scan_tiles + 1));
    CREATE_TRY(hipMemsetAsync(ctx->cell_count, 0, cells_padded * sizeof(uint32_t), ctx->stream));
+   CREATE_TRY(hipMemsetAsync(ctx->cell_start, 0, cells_padded * sizeof(uint32_t), ctx->stream));
    CREATE_TRY(dev_alloc(&ctx->rho, cap));
    CREATE_TRY(dev_alloc(&ctx->acc, cap));
    CREATE_TRY(dev_alloc(&ctx->ncount, cap));
    CREATE_TRY(hipMemsetAsync(ctx->rho, 0, cap * sizeof(float), ctx->stream));
    CREATE_TRY(hipMemsetAsync(ctx->acc, 0, cap * sizeof(float4), ctx->stream));
    CREATE_TRY(hipMemsetAsync(ctx->ncount, 0, cap * sizeof(int32_t), ctx->stream));
+   CREATE_TRY(dev_alloc(&ctx->meta, META_COUNT));
+   CREATE_TRY(hipMemsetAsync(ctx->meta, 0, META_COUNT * sizeof(int32_t), ctx->stream));
    if (mode == SPH_HIP_MODE_FULL) {
       CREATE_TRY(dev_alloc(&ctx->aux, cap));
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
@@ -406,11 +443,24 @@ int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capa
    CREATE_TRY(dev_alloc(&ctx->epart, (size_t)2 * ctx->eblocks + 2));
    CREATE_TRY(hipMemsetAsync(ctx->epart, 0, sizeof(double) * 2, ctx->stream));
    CREATE_TRY(dev_alloc(&ctx->stats, 4));
-   CREATE_TRY(dev_alloc(&ctx->stage, cap * 11));
+   CREATE_TRY(dev_alloc(&ctx->stage, cap * 12));
    CREATE_TRY(hipStreamSynchronize(ctx->stream));
 #undef CREATE_TRY
    *out = ctx;
    return SPH_HIP_OK;
+}
+
+int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
+                   int device)
+{
+   return create_impl(out, params, capacity, mode, device, 0, -1, 0);
+}
+
+int sph_hip_create_slab(sph_hip_context** out, const sph_hip_params* params, int capacity,
+                        int device, int plane_lo, int plane_hi)
+{
+   return create_impl(out, params, capacity, SPH_HIP_MODE_FULL, device, plane_lo, plane_hi,
+                      SPH_HIP_SLAB_HALO);
 }
 
 void sph_hip_destroy(sph_hip_context* ctx)
@@ -425,6 +475,15 @@ void sph_hip_destroy(sph_hip_context* ctx)
 const char* sph_hip_last_error(const sph_hip_context* ctx)
 {
    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int sph_hip_set_stream(sph_hip_context* ctx, void* hip_stream)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+   return SPH_HIP_OK;
 }
 
 int sph_hip_set_params(sph_hip_context* ctx, const sph_hip_params* p)
@@ -449,42 +508,110 @@ int sph_hip_get_params(const sph_hip_context* ctx, sph_hip_params* out)
    return SPH_HIP_OK;
 }
 
+// shared by sph_hip_upload (ids = 0..n-1) and sph_hip_slab_upload (caller's global ids)
+static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const float* vel,
+                       const float* mass, const uint32_t* ids, int uniform_mass)
+{
+   if (n < 0 || (n > 0 && (!pos || !vel || !mass))) {
+      ctx->err = "upload: null array or negative count";
+      return SPH_HIP_ERR_INVALID;
+   }
+   if (n > ctx->capacity) {
+      ctx->err = "upload: more particles than the context capacity";
+      return SPH_HIP_ERR_CAPACITY;
+   }
+   // a slab's entry count changes every step, so its launches are sized by the capacity
+   const bool whole = ctx->plane_lo == 0 && ctx->plane_hi == ctx->grid.nz_global;
+   ctx->n = whole ? n : ctx->capacity;
+   ctx->n_owned = n;
+   ctx->cur = 0;
+   ctx->uniform_mass = uniform_mass;
+   ctx->ev_steps = 0;
+   // before the first cell build everything uploaded is live and owned, in upload order
+   const int32_t meta[META_COUNT] = {n, n, 0, n, 0, n, 0, 0};
+   SPH_TRY(hipMemcpyAsync(ctx->meta, meta, sizeof(meta), hipMemcpyHostToDevice, ctx->stream));
+   if (n > 0) {
+      float* spos = ctx->stage;
+      float* svel = spos + 3 * (size_t)n;
+      float* smass = svel + 3 * (size_t)n;
+      uint32_t* sids = reinterpret_cast<uint32_t*>(smass + (size_t)n);
+      hipStream_t st = ctx->stream;
+      SPH_TRY(hipMemcpyAsync(spos, pos, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+      SPH_TRY(hipMemcpyAsync(svel, vel, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+      SPH_TRY(hipMemcpyAsync(smass, mass, sizeof(float) * n, hipMemcpyHostToDevice, st));
+      if (ids) SPH_TRY(hipMemcpyAsync(sids, ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_import, dim3(div_up(n, 256)), dim3(256), 0, st, spos, svel, smass,
+                         ids ? sids : (const uint32_t*)nullptr, n, ctx->posm[0], ctx->velp[0]);
+      SPH_TRY(hipGetLastError());
+   }
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
+static int all_same_mass(int n, const float* mass)
+{
+   for (int i = 1; i < n; i++)
+      if (memcmp(&mass[i], &mass[0], sizeof(float)) != 0) return 0;
+   return 1;
+}
+
 int sph_hip_upload(sph_hip_context* ctx, int n, const float* pos, const float* vel,
                    const float* mass)
 {
    int rc = check_ctx(ctx);
    if (rc) return rc;
-   if (n < 0 || !pos || !vel || !mass) {
-      ctx->err = "sph_hip_upload: null array or negative count";
-      return SPH_HIP_ERR_INVALID;
-   }
-   if (n > ctx->capacity) {
-      ctx->err = "sph_hip_upload: more particles than the context capacity";
-      return SPH_HIP_ERR_CAPACITY;
-   }
-   ctx->n = n;
-   ctx->n_owned = n;
-   ctx->cur = 0;
    // the reference gives every particle the same mass (src/sph.cpp:105-108); when the upload
    // does too, the tiled kernels skip the per-neighbour mass gather (bit-identical results)
-   ctx->uniform_mass = 1;
-   for (int i = 1; i < n; i++)
-      if (memcmp(&mass[i], &mass[0], sizeof(float)) != 0) {
-         ctx->uniform_mass = 0;
-         break;
-      }
-   ctx->ev_steps = 0;
+   return upload_impl(ctx, n, pos, vel, mass, nullptr, (n > 0 && mass) ? all_same_mass(n, mass) : 0);
+}
+
+int sph_hip_slab_upload(sph_hip_context* ctx, int n, const float* pos, const float* vel,
+                        const float* mass, const uint32_t* ids, int all_masses_equal)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || (n > 0 && !ids)) {
+      ctx->err = "sph_hip_slab_upload: FULL-mode contexts only, ids required";
+      return SPH_HIP_ERR_INVALID;
+   }
+   return upload_impl(ctx, n, pos, vel, mass, ids, all_masses_equal ? 1 : 0);
+}
+
+// owned count right now (device value); synchronises the stream
+static int owned_count(sph_hip_context* ctx, int32_t* meta_out)
+{
+   int32_t meta[META_COUNT];
+   SPH_TRY(hipMemcpyAsync(meta, ctx->meta, sizeof(meta), hipMemcpyDeviceToHost, ctx->stream));
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   if (meta_out) memcpy(meta_out, meta, sizeof(meta));
+   ctx->n_owned = meta[META_OWN_END] - meta[META_OWN_BEGIN];
+   return SPH_HIP_OK;
+}
+
+static int download_impl(sph_hip_context* ctx, int compact, int n, uint32_t* ids, float* pos,
+                         float* vel, float* density, float* acc, int32_t* neighbor_count)
+{
    if (n == 0) return SPH_HIP_OK;
    float* spos = ctx->stage;
    float* svel = spos + 3 * (size_t)n;
-   float* smass = svel + 3 * (size_t)n;
-   SPH_TRY(hipMemcpyAsync(spos, pos, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-   SPH_TRY(hipMemcpyAsync(svel, vel, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-   SPH_TRY(hipMemcpyAsync(smass, mass, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
-   hipLaunchKernelGGL(k_import, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, spos, svel, smass,
-                      n, ctx->posm[0], ctx->velp[0]);
+   float* srho = svel + 3 * (size_t)n;
+   float* sacc = srho + (size_t)n;
+   int32_t* scnt = reinterpret_cast<int32_t*>(sacc + 3 * (size_t)n);
+   uint32_t* sids = reinterpret_cast<uint32_t*>(scnt + (size_t)n);
+   hipStream_t st = ctx->stream;
+   hipLaunchKernelGGL(k_export, dim3(div_up(ctx->n, 256)), dim3(256), 0, st, ctx->posm[ctx->cur],
+                      ctx->velp[ctx->cur], ctx->rho, ctx->acc, ctx->ncount, ctx->meta, compact,
+                      pos ? spos : nullptr, vel ? svel : nullptr, density ? srho : nullptr,
+                      acc ? sacc : nullptr, neighbor_count ? scnt : nullptr, ids ? sids : nullptr);
    SPH_TRY(hipGetLastError());
-   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   if (pos) SPH_TRY(hipMemcpyAsync(pos, spos, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+   if (vel) SPH_TRY(hipMemcpyAsync(vel, svel, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+   if (density) SPH_TRY(hipMemcpyAsync(density, srho, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+   if (acc) SPH_TRY(hipMemcpyAsync(acc, sacc, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+   if (neighbor_count)
+      SPH_TRY(hipMemcpyAsync(neighbor_count, scnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+   if (ids) SPH_TRY(hipMemcpyAsync(ids, sids, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+   SPH_TRY(hipStreamSynchronize(st));
    return SPH_HIP_OK;
 }
 
@@ -493,26 +620,82 @@ int sph_hip_download(sph_hip_context* ctx, float* pos, float* vel, float* densit
 {
    int rc = check_ctx(ctx);
    if (rc) return rc;
-   const int n = ctx->n_owned;
-   if (n == 0) return SPH_HIP_OK;
-   float* spos = ctx->stage;
-   float* svel = spos + 3 * (size_t)n;
-   float* srho = svel + 3 * (size_t)n;
-   float* sacc = srho + (size_t)n;
-   int32_t* scnt = reinterpret_cast<int32_t*>(sacc + 3 * (size_t)n);
-   hipLaunchKernelGGL(k_export, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream,
-                      ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->acc, ctx->ncount, n,
-                      pos ? spos : nullptr, vel ? svel : nullptr, density ? srho : nullptr,
-                      acc ? sacc : nullptr, neighbor_count ? scnt : nullptr);
-   SPH_TRY(hipGetLastError());
+   if (!(ctx->plane_lo == 0 && ctx->plane_hi == ctx->grid.nz_global)) {
+      ctx->err = "sph_hip_download: slab contexts use sph_hip_slab_download";
+      return SPH_HIP_ERR_INVALID;
+   }
+   return download_impl(ctx, 0, ctx->n_owned, nullptr, pos, vel, density, acc, neighbor_count);
+}
+
+int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uint32_t* ids,
+                          float* pos, float* vel, float* density, float* acc,
+                          int32_t* neighbor_count)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if ((rc = owned_count(ctx, nullptr))) return rc;
+   if (rows) *rows = ctx->n_owned;
+   if (ctx->n_owned > max_rows) {
+      ctx->err = "sph_hip_slab_download: caller's arrays are too small";
+      return SPH_HIP_ERR_CAPACITY;
+   }
+   return download_impl(ctx, 1, ctx->n_owned, ids, pos, vel, density, acc, neighbor_count);
+}
+
+int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   int32_t meta[META_COUNT];
+   if ((rc = owned_count(ctx, meta))) return rc;
+   if (live) *live = meta[META_N_LIVE];
+   if (owned) *owned = meta[META_OWN_END] - meta[META_OWN_BEGIN];
+   if (errors) *errors = meta[META_ERRORS];
+   return SPH_HIP_OK;
+}
+
+size_t sph_hip_slab_message_bytes(int capacity_records)
+{
+   return sizeof(int32_t) * SLAB_HEADER_INTS + (size_t)capacity_records * 2 * sizeof(float4);
+}
+
+int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_device,
+                      int capacity_records)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
    hipStream_t st = ctx->stream;
-   if (pos) SPH_TRY(hipMemcpyAsync(pos, spos, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
-   if (vel) SPH_TRY(hipMemcpyAsync(vel, svel, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
-   if (density) SPH_TRY(hipMemcpyAsync(density, srho, sizeof(float) * n, hipMemcpyDeviceToHost, st));
-   if (acc) SPH_TRY(hipMemcpyAsync(acc, sacc, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
-   if (neighbor_count)
-      SPH_TRY(hipMemcpyAsync(neighbor_count, scnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-   SPH_TRY(hipStreamSynchronize(st));
+   if (left_device) SPH_TRY(hipMemsetAsync(left_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
+   if (right_device) SPH_TRY(hipMemsetAsync(right_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
+   hipLaunchKernelGGL(k_slab_pack, dim3(div_up(ctx->n, 256)), dim3(256), 0, st, ctx->posm[ctx->cur],
+                      ctx->velp[ctx->cur], ctx->meta, ctx->grid, ctx->plane_lo, ctx->plane_hi,
+                      ctx->halo, left_device ? 1 : 0, right_device ? 1 : 0,
+                      (SlabMsg*)left_device, (SlabMsg*)right_device, capacity_records);
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const void* right_device,
+                        int capacity_records)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
+   hipStream_t st = ctx->stream;
+   const SlabMsg* msgs[2] = {(const SlabMsg*)left_device, (const SlabMsg*)right_device};
+   // entries behind the live ones: start from n_in = n_live, append one message after the other
+   hipLaunchKernelGGL(k_slab_set_n_in, dim3(1), dim3(1), 0, st, ctx->meta, msgs[0], msgs[1],
+                      ctx->capacity, capacity_records, 0);
+   for (int s = 0; s < 2; s++) {
+      if (!msgs[s]) continue;
+      hipLaunchKernelGGL(k_slab_unpack, dim3(div_up(capacity_records, 256)), dim3(256), 0, st,
+                         msgs[s], ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->meta,
+                         (int)META_N_IN, ctx->capacity, capacity_records);
+      hipLaunchKernelGGL(k_slab_set_n_in, dim3(1), dim3(1), 0, st, ctx->meta, msgs[0], msgs[1],
+                         ctx->capacity, capacity_records, s + 1);
+   }
+   SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
 }
 
@@ -630,6 +813,7 @@ int sph_hip_get_neighbor_stats(sph_hip_context* ctx, int32_t* avg, int32_t* mx, 
 {
    int rc = check_ctx(ctx);
    if (rc) return rc;
+   if ((rc = owned_count(ctx, nullptr))) return rc;
    const int n = ctx->n_owned;
    if (n == 0) return SPH_HIP_ERR_INVALID;
    const int32_t init[4] = {0, 0, -1, 34};
@@ -637,7 +821,7 @@ int sph_hip_get_neighbor_stats(sph_hip_context* ctx, int32_t* avg, int32_t* mx, 
    int blocks = div_up(n, RED_THREADS);
    if (blocks > 1024) blocks = 1024;
    hipLaunchKernelGGL(k_neighbor_stats, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
-                      ctx->ncount, n, ctx->stats);
+                      ctx->ncount, ctx->meta, ctx->stats);
    SPH_TRY(hipGetLastError());
    int32_t out[4];
    SPH_TRY(hipMemcpyAsync(out, ctx->stats, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
@@ -657,7 +841,7 @@ int sph_hip_download_voxels(sph_hip_context* ctx, int32_t* coords_xyz, int32_t* 
       ctx->err = "sph_hip_download_voxels: REF-mode contexts only";
       return SPH_HIP_ERR_INVALID;
    }
-   const int n = ctx->n;
+   const int n = ctx->n_owned;
    if (coords_xyz)
       SPH_TRY(hipMemcpyAsync(coords_xyz, ctx->vox, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost,
                              ctx->stream));
@@ -697,7 +881,7 @@ int sph_hip_download_neighbor_lists(sph_hip_context* ctx, uint32_t* neighbors, f
       ctx->err = "sph_hip_download_neighbor_lists: REF-mode contexts only (FULL mode stores no lists)";
       return SPH_HIP_ERR_INVALID;
    }
-   const size_t m = (size_t)ctx->n * ctx->prm.examine_count;
+   const size_t m = (size_t)ctx->n_owned * ctx->prm.examine_count;
    if (neighbors)
       SPH_TRY(hipMemcpyAsync(neighbors, ctx->nb, sizeof(uint32_t) * m, hipMemcpyDeviceToHost,
                              ctx->stream));

@@ -78,6 +78,16 @@ PROTOTYPES = {
     "sph_hip_download_grid_counts": (C.c_int, [_ctx, C.c_void_p]),
     "sph_hip_download_neighbor_lists": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "sph_hip_stream": (C.c_void_p, [_ctx]),
+    "sph_hip_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "sph_hip_create_slab": (C.c_int, [_P(_ctx), _P(SphParams), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sph_hip_slab_upload": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int]),
+    "sph_hip_slab_download": (C.c_int, [_ctx, C.c_int, _P(C.c_int32), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sph_hip_slab_message_bytes": (C.c_size_t, [C.c_int]),
+    "sph_hip_slab_pack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
+    "sph_hip_slab_unpack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
+    "sph_hip_slab_status": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
 }
 
 _LIB = None

@@ -1,0 +1,290 @@
+"""1-D slab decomposition of the FULL-mode step across GPUs.
+
+The reference is single-process; this is the multi-GPU counterpart of its
+`SPH::run()` loop.  One slab per GPU owns a range of global z-planes of the FULL cell grid
+(include/sph_hip.h, "multi-GPU" section).  Per step each slab packs one message per neighbour
+on the device, the transport moves the two messages (RCCL send/recv over xGMI through
+`torch.distributed`, backend "nccl"; or plain pointer hand-over between slabs that live in one
+process), the slab unpacks what it received and steps.  There is no collective in the data
+path: each slab talks to its two neighbours only.
+
+The orchestration here is backend-agnostic: `HipSlab` drives the HIP library; the tests plug a
+CPU stand-in with the same five methods to exercise planning, message flow and the
+torch.distributed transport under gloo.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .lib import SphHipError, load_library
+
+HALO = 2
+HEADER_BYTES = 32
+RECORD_BYTES = 32
+
+
+# ---- planning ---------------------------------------------------------------------------------
+
+def plane_of(params, z):
+    """Global FULL-grid z-plane of each z coordinate — same arithmetic as the device
+    (fp32 multiply, floor, clamp)."""
+    z = np.asarray(z, np.float32)
+    c = np.floor(z * np.float32(params.full_cell_inv))
+    c = np.where(np.isfinite(c), c, -1.0)
+    return np.clip(c, 0, params.full_cells_z - 1).astype(np.int64)
+
+
+def plan_cuts(params, z, world, min_planes=2 * HALO):
+    """Cut planes [c0=0, c1, ..., c_world=nz] that balance the particle count per slab.
+
+    Every slab gets at least `min_planes` planes (a slab must be at least as thick as the two
+    halos it feeds).  Deterministic: every rank computes the same cuts from the same z."""
+    nz = params.full_cells_z
+    if world * min_planes > nz:
+        raise ValueError("grid has %d planes: too few for %d slabs of >= %d planes" %
+                         (nz, world, min_planes))
+    hist = np.bincount(plane_of(params, z), minlength=nz).astype(np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(hist)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        c = int(np.searchsorted(cum, target, side="left"))
+        c = max(c, cuts[-1] + min_planes)
+        c = min(c, nz - (world - r) * min_planes)
+        cuts.append(c)
+    cuts.append(nz)
+    return cuts
+
+
+def message_bytes(capacity_records):
+    return HEADER_BYTES + capacity_records * RECORD_BYTES
+
+
+# ---- one slab on one GPU ------------------------------------------------------------------------
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HipSlab:
+    """A slab context of libsph_hip.so (sph_hip_create_slab) plus its message buffers."""
+
+    def __init__(self, params, plane_lo, plane_hi, capacity, msg_capacity, device=0,
+                 has_left=True, has_right=True, stream=None):
+        import torch
+        self._torch = torch
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        self.params = params.copy()
+        self.plane_lo, self.plane_hi = int(plane_lo), int(plane_hi)
+        self.capacity, self.msg_capacity = int(capacity), int(msg_capacity)
+        self.device = torch.device("cuda", device)
+        rc = self._lib.sph_hip_create_slab(C.byref(self._ctx), C.byref(self.params), self.capacity,
+                                           int(device), self.plane_lo, self.plane_hi)
+        if rc != 0:
+            msg = self._lib.sph_hip_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise SphHipError("sph_hip_create_slab failed (%d): %s" % (rc, msg))
+        # All launches of this slab go to ONE torch stream (a real stream object: torch's default
+        # stream has the NULL handle, which the C ABI reads as "use the context's own stream").
+        # torch.distributed orders its RCCL calls against the stream that is current when they
+        # are issued, so the transport runs under `with torch.cuda.stream(self.stream)`; slabs
+        # sharing a process share the stream, which orders pack(r) before unpack(r+1).
+        with torch.cuda.device(self.device):
+            self.stream = stream if stream is not None else torch.cuda.Stream()
+        self._check(self._lib.sph_hip_set_stream(self._ctx, C.c_void_p(self.stream.cuda_stream)),
+                    "set_stream")
+        nbytes = message_bytes(self.msg_capacity)
+        with torch.cuda.stream(self.stream):
+            mk = lambda on: (torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+                             if on else None)
+            self.send_left, self.send_right = mk(has_left), mk(has_right)
+            self.recv_left, self.recv_right = mk(has_left), mk(has_right)
+        self.stream.synchronize()
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.sph_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.sph_hip_last_error(self._ctx).decode()
+            raise SphHipError("%s failed (%d): %s" % (what, rc, msg))
+
+    def upload(self, ids, pos, vel, mass, all_masses_equal):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1)
+        vel = np.ascontiguousarray(vel, np.float32).reshape(-1)
+        mass = np.ascontiguousarray(mass, np.float32)
+        self._check(self._lib.sph_hip_slab_upload(self._ctx, ids.size, _ptr(pos), _ptr(vel),
+                                                  _ptr(mass), _ptr(ids), int(all_masses_equal)),
+                    "sph_hip_slab_upload")
+
+    @staticmethod
+    def _dp(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def pack(self):
+        self._check(self._lib.sph_hip_slab_pack(self._ctx, self._dp(self.send_left),
+                                                self._dp(self.send_right), self.msg_capacity),
+                    "sph_hip_slab_pack")
+
+    def unpack(self, recv_left=None, recv_right=None):
+        left = recv_left if recv_left is not None else self.recv_left
+        right = recv_right if recv_right is not None else self.recv_right
+        self._check(self._lib.sph_hip_slab_unpack(self._ctx, self._dp(left), self._dp(right),
+                                                  self.msg_capacity), "sph_hip_slab_unpack")
+
+    def step(self):
+        self._check(self._lib.sph_hip_step(self._ctx), "sph_hip_step")
+
+    def synchronize(self):
+        self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
+
+    def status(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.sph_hip_slab_status(self._ctx, C.byref(a), C.byref(b), C.byref(c)),
+                    "sph_hip_slab_status")
+        return dict(live=a.value, owned=b.value, errors=c.value)
+
+    def download(self):
+        rows = C.c_int32()
+        cap = self.capacity
+        out = dict(ids=np.zeros(cap, np.uint32), pos=np.zeros(3 * cap, np.float32),
+                   vel=np.zeros(3 * cap, np.float32), rho=np.zeros(cap, np.float32),
+                   acc=np.zeros(3 * cap, np.float32), ncount=np.zeros(cap, np.int32))
+        self._check(self._lib.sph_hip_slab_download(self._ctx, cap, C.byref(rows), _ptr(out["ids"]),
+                                                    _ptr(out["pos"]), _ptr(out["vel"]),
+                                                    _ptr(out["rho"]), _ptr(out["acc"]),
+                                                    _ptr(out["ncount"])), "sph_hip_slab_download")
+        n = rows.value
+        return dict(ids=out["ids"][:n], pos=out["pos"][:3 * n], vel=out["vel"][:3 * n],
+                    rho=out["rho"][:n], acc=out["acc"][:3 * n], ncount=out["ncount"][:n])
+
+    def phase_totals(self):
+        ms = (C.c_double * 6)()
+        k = C.c_int32()
+        self._check(self._lib.sph_hip_get_phase_totals(self._ctx, C.byref(ms), C.byref(k)),
+                    "sph_hip_get_phase_totals")
+        return list(ms), k.value
+
+    def reset_timings(self):
+        self._check(self._lib.sph_hip_reset_timings(self._ctx), "sph_hip_reset_timings")
+
+    def energy(self):
+        ke, pe = C.c_float(), C.c_float()
+        self._check(self._lib.sph_hip_get_energy(self._ctx, C.byref(ke), C.byref(pe)),
+                    "sph_hip_get_energy")
+        return ke.value, pe.value
+
+
+# ---- orchestration ------------------------------------------------------------------------------
+
+def split_scene(params, cuts, rank, pos, vel, mass):
+    """The particles (with their global ids) that slab `rank` owns initially."""
+    pl = plane_of(params, np.asarray(pos, np.float32).reshape(-1, 3)[:, 2])
+    mine = np.nonzero((pl >= cuts[rank]) & (pl < cuts[rank + 1]))[0]
+    pos3 = np.asarray(pos, np.float32).reshape(-1, 3)
+    vel3 = np.asarray(vel, np.float32).reshape(-1, 3)
+    return (mine.astype(np.uint32), np.ascontiguousarray(pos3[mine]).reshape(-1),
+            np.ascontiguousarray(vel3[mine]).reshape(-1), np.ascontiguousarray(mass[mine]))
+
+
+def slab_capacities(counts_per_plane, cuts, rank, slack=1.5):
+    """(entry capacity, message capacity) for a slab from the initial plane histogram."""
+    lo, hi = cuts[rank], cuts[rank + 1]
+    nz = counts_per_plane.size
+    held = counts_per_plane[max(lo - HALO, 0):min(hi + HALO, nz)].sum()
+    left = counts_per_plane[lo:min(lo + HALO, nz)].sum()
+    right = counts_per_plane[max(hi - HALO, 0):hi].sum()
+    cap = int(held * slack) + 4096
+    msg = int(max(left, right) * slack * 1.5) + 4096
+    return cap, msg
+
+
+class DistTransport:
+    """Neighbour exchange over torch.distributed point-to-point ops (RCCL when the backend is
+    "nccl": each slab pair has its own xGMI link).  One batch per step: send left/right,
+    receive left/right."""
+
+    def __init__(self, rank, world, group=None):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
+
+    def exchange(self, slab):
+        dist = self.dist
+        ops = []
+        left, right = self.rank - 1, self.rank + 1
+        if left >= 0:
+            ops.append(dist.P2POp(dist.isend, slab.send_left, left, self.group))
+            ops.append(dist.P2POp(dist.irecv, slab.recv_left, left, self.group))
+        if right < self.world:
+            ops.append(dist.P2POp(dist.isend, slab.send_right, right, self.group))
+            ops.append(dist.P2POp(dist.irecv, slab.recv_right, right, self.group))
+        if not ops:
+            return
+        stream = getattr(slab, "stream", None)
+        if stream is not None:
+            import torch
+            with torch.cuda.stream(stream):   # RCCL work is ordered against the slab's stream
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        else:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+class DistSlabStepper:
+    """The per-rank loop body: pack -> exchange -> unpack -> step."""
+
+    def __init__(self, slab, transport):
+        self.slab, self.transport = slab, transport
+
+    def step(self):
+        self.slab.pack()
+        self.transport.exchange(self.slab)
+        self.slab.unpack()
+        self.slab.step()
+
+
+class LocalSlabGroup:
+    """All slabs in ONE process (e.g. on one GPU): the messages are handed over by pointer.
+    Same kernels and message format as the distributed run; used to check on a single GPU that
+    results do not depend on the number of slabs."""
+
+    def __init__(self, slabs):
+        self.slabs = slabs
+
+    def step(self):
+        for s in self.slabs:
+            s.pack()
+        for r, s in enumerate(self.slabs):
+            left = self.slabs[r - 1].send_right if r > 0 else None
+            right = self.slabs[r + 1].send_left if r + 1 < len(self.slabs) else None
+            s.unpack(left, right)
+        for s in self.slabs:
+            s.step()
+
+    def gather(self, n_total):
+        """Per-id arrays assembled from every slab's owned particles."""
+        out = dict(pos=np.zeros(3 * n_total, np.float32), vel=np.zeros(3 * n_total, np.float32),
+                   rho=np.zeros(n_total, np.float32), acc=np.zeros(3 * n_total, np.float32),
+                   ncount=np.zeros(n_total, np.int32), owner=np.full(n_total, -1, np.int32))
+        for r, s in enumerate(self.slabs):
+            d = s.download()
+            ids = d["ids"].astype(np.int64)
+            assert (out["owner"][ids] == -1).all(), "a particle is owned by two slabs"
+            out["owner"][ids] = r
+            for k in ("pos", "vel", "acc"):
+                out[k].reshape(-1, 3)[ids] = d[k].reshape(-1, 3)
+            out["rho"][ids] = d["rho"]
+            out["ncount"][ids] = d["ncount"]
+        return out

@@ -1,0 +1,116 @@
+"""GPU: the slab-decomposed FULL-mode step (what runs one-slab-per-GPU over RCCL) against the
+single-context step and the oracle.  All slabs live on the one GPU of the test box and hand
+their messages over by pointer (LocalSlabGroup) — kernels, message format and ghost/migrant
+protocol are exactly those of the distributed run; only the transport differs (that part is
+covered under gloo in test_slab_cpu.py).  Bar: bit-identical per-particle results for any
+number of slabs."""
+import numpy as np
+import pytest
+
+from helpers import to_oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def build_group(S, p, pos, vel, mass, world):
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    z = pos.reshape(-1, 3)[:, 2]
+    cuts = SL.plan_cuts(p, z, world)
+    hist = np.bincount(SL.plane_of(p, z), minlength=p.full_cells_z)
+    uniform = bool((mass == mass[0]).all())
+    import torch
+    stream = torch.cuda.Stream()     # slabs of one process share one stream
+    slabs = []
+    for r in range(world):
+        cap, msg = SL.slab_capacities(hist, cuts, r, slack=2.0)
+        s = SL.HipSlab(p, cuts[r], cuts[r + 1], cap, msg, device=0, has_left=r > 0,
+                       has_right=r + 1 < world, stream=stream)
+        s.upload(*SL.split_scene(p, cuts, r, pos, vel, mass), all_masses_equal=uniform)
+        slabs.append(s)
+    return SL.LocalSlabGroup(slabs), cuts
+
+
+def moving_block(n=30000, speed=40.0, unequal=True):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(n, lo=(1.0, 1.0, 1.0), hi=(2.2, 2.2, 2.8), speed=speed)
+    if unequal:
+        mass = (0.5 + scenes.uniform01(11, np.arange(n))).astype(np.float32)
+    return p, pos, vel, mass
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+def test_slabs_equal_single_context_and_oracle(oracle, hiplib, world):
+    import smoothed_particle_hydrodynamics_amd as S
+    p, pos, vel, mass = moving_block()
+    steps = 5
+    group, cuts = build_group(S, p, pos, vel, mass, world)
+    owned0 = [s.status()["owned"] for s in group.slabs]
+    for _ in range(steps):
+        group.step()
+    got = group.gather(mass.size)
+    assert (got["owner"] >= 0).all()
+    for s in group.slabs:
+        assert s.status()["errors"] == 0
+
+    opos, ovel = pos.copy(), vel.copy()
+    for _ in range(steps):
+        ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+    assert np.array_equal(got["ncount"], ref["ncount"])
+    assert np.array_equal(got["rho"], ref["rho"])
+    assert np.array_equal(got["acc"], ref["acc"])
+    assert np.array_equal(got["pos"], opos)
+    assert np.array_equal(got["vel"], ovel)
+
+    with S.SPH(mass.size, p) as one:
+        one.setParticles(pos, vel, mass)
+        one.run(steps)
+        part = one.getParticles()
+        assert np.array_equal(got["acc"], part.mAcceleration)
+        assert np.array_equal(got["pos"], part.mPosition)
+
+    if world > 1:
+        owned1 = [s.status()["owned"] for s in group.slabs]
+        assert sum(owned1) == mass.size
+        assert owned0 != owned1, "the scene is meant to migrate particles across the cuts"
+    for s in group.slabs:
+        s.close()
+
+
+def test_slabs_dam_break_uniform_mass_two_slabs(oracle, hiplib):
+    """the benchmark scene (uniform masses -> fast path), 2 slabs, 3 steps"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(120000)
+    group, cuts = build_group(S, p, pos, vel, mass, 2)
+    for _ in range(3):
+        group.step()
+    got = group.gather(mass.size)
+    opos, ovel = pos.copy(), vel.copy()
+    for _ in range(3):
+        ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+    for k, want in (("ncount", ref["ncount"]), ("rho", ref["rho"]), ("acc", ref["acc"]),
+                    ("pos", opos), ("vel", ovel)):
+        assert np.array_equal(got[k], want), k
+    for s in group.slabs:
+        assert s.status()["errors"] == 0
+        s.close()
+
+
+def test_message_overflow_is_reported(hiplib):
+    """a message buffer that is too small sets error bit 2 instead of corrupting memory"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    p, pos, vel, mass = moving_block(20000, unequal=False)
+    cuts = SL.plan_cuts(p, pos.reshape(-1, 3)[:, 2], 2)
+    import torch
+    stream = torch.cuda.Stream()
+    slabs = []
+    for r in range(2):
+        s = SL.HipSlab(p, cuts[r], cuts[r + 1], 60000, 16, device=0, has_left=r > 0, has_right=r < 1,
+                       stream=stream)
+        s.upload(*SL.split_scene(p, cuts, r, pos, vel, mass), all_masses_equal=True)
+        slabs.append(s)
+    SL.LocalSlabGroup(slabs).step()
+    assert any(s.status()["errors"] & 2 for s in slabs)
+    for s in slabs:
+        s.close()
