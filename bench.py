@@ -67,6 +67,80 @@ def cpu_baseline(n_sample, steps, n_total):
     }
 
 
+def run_single(args, S, scenes, torch, local_rank):
+    """N = 1: one context holds the whole grid."""
+    n = args.particles
+    p, pos, vel, mass = scenes.dam_break(n)
+    sph = S.SPH(n, p, mode=S.MODE_FULL, device=local_rank)
+    sph.setParticles(pos, vel, mass)
+    for _ in range(args.warmup):
+        sph.step()
+    sph.synchronize()
+    torch.cuda.synchronize()
+    sph.resetTimings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sph.step()
+    sph.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    totals, covered = sph.phaseTotals()
+    nb_mean = float(sph.getParticles().mNeighborCount.mean())
+    ke, pe = sph.energy()
+    assert np.isfinite(ke) and np.isfinite(pe)
+    return p, dt, totals, covered, n, nb_mean, "1 GPU"
+
+
+def run_slabs(args, S, scenes, torch, rank, world, local_rank):
+    """N > 1: one z-slab of the cell grid per GPU, neighbour exchange over RCCL (xGMI)."""
+    import torch.distributed as dist
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    n = args.particles
+    p, pos, vel, mass = scenes.dam_break(n)       # every rank derives the same scene and cuts
+    z = pos.reshape(-1, 3)[:, 2]
+    cuts = SL.plan_cuts(p, z, world)
+    hist = np.bincount(SL.plane_of(p, z), minlength=p.full_cells_z)
+    cap, msg = SL.slab_capacities(hist, cuts, rank, slack=1.5)
+    slab = SL.HipSlab(p, cuts[rank], cuts[rank + 1], cap, msg, device=local_rank,
+                      has_left=rank > 0, has_right=rank + 1 < world)
+    slab.upload(*SL.split_scene(p, cuts, rank, pos, vel, mass), all_masses_equal=True)
+    # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P)
+    host = os.environ.get("SPH_SLAB_TRANSPORT") == "host"
+    transport = (SL.HostStagedTransport if host else SL.DistTransport)(rank, world)
+    stepper = SL.DistSlabStepper(slab, transport)
+
+    def fence():
+        slab.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    for _ in range(args.warmup):
+        stepper.step()
+    fence()
+    slab.reset_timings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step()
+    fence()
+    dt_local = time.perf_counter() - t0
+    t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    st = slab.status()
+    flags = torch.tensor([st["errors"], st["owned"]], dtype=torch.int64, device="cuda")
+    err = flags[:1].clone()
+    dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    own = flags[1:].clone()
+    dist.all_reduce(own, op=dist.ReduceOp.SUM)
+    if int(err.item()) != 0 or int(own.item()) != n:
+        raise SystemExit("slab run inconsistent: error bits %d, owned %d of %d" %
+                         (int(err.item()), int(own.item()), n))
+    totals, covered = slab.phase_totals()
+    d = slab.download()
+    nb_mean = float(d["ncount"].mean())
+    return p, dt, totals, covered, st["owned"], nb_mean, "z-slab x%d, RCCL halo" % world
+
+
 def main():
     args = parse_args()
     import torch
@@ -76,81 +150,86 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SPH_BENCH_ONE_DEVICE") == "1":   # rehearsal: all ranks share device 0
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
-    if world > 1:
-        raise SystemExit("multi-GPU slab decomposition is not wired into bench.py yet")
-
     torch.cuda.set_device(local_rank)
-    S.build_library()
+    if rank == 0:
+        S.build_library()
     n = args.particles
-    p, pos, vel, mass = scenes.dam_break(n)
-    sph = S.SPH(n, p, mode=S.MODE_FULL, device=local_rank)
-    sph.setParticles(pos, vel, mass)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("SPH_SLAB_TRANSPORT") == "host":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+        p, dt, totals, covered, n_rank, nb_mean, par = run_slabs(args, S, scenes, torch, rank,
+                                                                 world, local_rank)
+    else:
+        p, dt, totals, covered, n_rank, nb_mean, par = run_single(args, S, scenes, torch,
+                                                                  local_rank)
 
-    for _ in range(args.warmup):
-        sph.step()
-    sph.synchronize()
-    torch.cuda.synchronize()
-    sph.resetTimings()
-
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sph.step()
-    sph.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
-    totals, covered = sph.phaseTotals()
-    # phases: 0 voxelize(cell build) 1 findNeighbors 2 density 3 pressure 4 acceleration 5 integrate
-    df_ms = (totals[2] + totals[4]) / covered
-    achieved = DENSITY_FORCE_BYTES * n / (df_ms * 1e-3) / 1e9
-    nb_mean = float(sph.getParticles().mNeighborCount.mean())
-    ke, pe = sph.energy()
-
-    line = {
-        "metric": "Mparticle-steps/sec (whole node), dam-break",
-        "value": n * args.steps / dt / 1e6,
-        "unit": "Mparticle-steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": "dam-break %d particles (BASELINE configs[2], C3) in the unit box, fp32, "
-                        "FULL neighbour mode, cell grid rebuilt every step" % n,
-            "particles": n,
-            "h": float(p.h),
-            "grid": [p.full_cells_x, p.full_cells_y, p.full_cells_z],
-            "neighbors_mean": nb_mean,
-            "parallelism": "1 GPU" if world == 1 else "slab x%d" % world,
-        },
-        "phases_ms": {
-            "cell_build": totals[0] / covered, "density": totals[2] / covered,
-            "acceleration": totals[4] / covered, "integrate": totals[5] / covered,
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "density+acceleration pass (k_full_density + k_full_accel)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "bytes_per_particle": DENSITY_FORCE_BYTES,
-            "ms_per_launch_pair": df_ms,
-        },
-    }
-    if args.cpu_sample > 0:
-        line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
-    assert np.isfinite(ke) and np.isfinite(pe)
-    print(json.dumps(line))
+    if rank == 0:
+        # phases: 0 cell build, 1 findNeighbors (fused), 2 density, 3 pressure (empty),
+        # 4 acceleration, 5 integrate — HIP events on the context's stream over the timed steps
+        df_ms = (totals[2] + totals[4]) / covered
+        achieved = DENSITY_FORCE_BYTES * n_rank / (df_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mparticle-steps/sec (whole node), dam-break",
+            "value": n * args.steps / dt / 1e6,
+            "unit": "Mparticle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "dam-break %d particles%s in the unit box, fp32, FULL neighbour "
+                            "mode, cell grid rebuilt every step" % (
+                                n, {262144: " (BASELINE configs[1], C2)",
+                                    4194304: " (BASELINE configs[2], C3)",
+                                    16777216: " (BASELINE configs[3], C4)"}.get(n, "")),
+                "particles": n,
+                "h": float(p.h),
+                "grid": [p.full_cells_x, p.full_cells_y, p.full_cells_z],
+                "neighbors_mean": nb_mean,
+                "parallelism": par,
+            },
+            "phases_ms": {
+                "cell_build": totals[0] / covered, "density": totals[2] / covered,
+                "acceleration": totals[4] / covered, "integrate": totals[5] / covered,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "density+acceleration pass (k_full_tiled<.,.,0> + k_full_tiled<.,.,1>)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_particle": DENSITY_FORCE_BYTES,
+                "particles_per_launch": n_rank,
+                "ms_per_launch_pair": df_ms,
+                "note": "VALU-bound gather-sum: see DESIGN.md (Roofline); frac is against the "
+                        "64 B/particle compulsory-traffic figure of SURVEY.md 8(d)",
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -199,14 +199,19 @@ def split_scene(params, cuts, rank, pos, vel, mass):
 
 
 def slab_capacities(counts_per_plane, cuts, rank, slack=1.5):
-    """(entry capacity, message capacity) for a slab from the initial plane histogram."""
-    lo, hi = cuts[rank], cuts[rank + 1]
+    """(entry capacity of slab `rank`, message capacity) from the initial plane histogram.
+
+    The message capacity is the same on every rank (a sender's and its receiver's buffers must
+    have one size): it covers the fullest halo strip next to any cut."""
     nz = counts_per_plane.size
+    lo, hi = cuts[rank], cuts[rank + 1]
     held = counts_per_plane[max(lo - HALO, 0):min(hi + HALO, nz)].sum()
-    left = counts_per_plane[lo:min(lo + HALO, nz)].sum()
-    right = counts_per_plane[max(hi - HALO, 0):hi].sum()
     cap = int(held * slack) + 4096
-    msg = int(max(left, right) * slack * 1.5) + 4096
+    strip = 0
+    for c in cuts[1:-1]:
+        strip = max(strip, counts_per_plane[max(c - HALO, 0):c].sum(),
+                    counts_per_plane[c:min(c + HALO, nz)].sum())
+    msg = int(strip * slack * 1.5) + 4096
     return cap, msg
 
 
@@ -240,6 +245,35 @@ class DistTransport:
         else:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+
+
+class HostStagedTransport(DistTransport):
+    """Same exchange with the messages staged through host memory (for process groups without
+    device-to-device P2P, e.g. gloo; used to rehearse the multi-rank path on one GPU)."""
+
+    def exchange(self, slab):
+        import torch
+        dist = self.dist
+        left, right = self.rank - 1, self.rank + 1
+        with torch.cuda.stream(slab.stream):
+            sends = {k: (getattr(slab, "send_" + k).cpu() if getattr(slab, "send_" + k) is not None
+                         else None) for k in ("left", "right")}
+        slab.stream.synchronize()
+        recvs = {k: (torch.empty_like(v) if v is not None else None) for k, v in sends.items()}
+        ops = []
+        if left >= 0:
+            ops.append(dist.P2POp(dist.isend, sends["left"], left, self.group))
+            ops.append(dist.P2POp(dist.irecv, recvs["left"], left, self.group))
+        if right < self.world:
+            ops.append(dist.P2POp(dist.isend, sends["right"], right, self.group))
+            ops.append(dist.P2POp(dist.irecv, recvs["right"], right, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        with torch.cuda.stream(slab.stream):
+            for k in ("left", "right"):
+                if recvs[k] is not None:
+                    getattr(slab, "recv_" + k).copy_(recvs[k], non_blocking=False)
 
 
 class DistSlabStepper:
