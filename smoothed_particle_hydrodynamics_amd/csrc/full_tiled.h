@@ -26,7 +26,7 @@
 #include "full_kernels.h"
 
 #define TILE_THREADS 256
-#define TILE_CAP 2688   // candidate positions per workgroup tile (3 x 10.5 KiB)
+#define TILE_CAP 3008   // candidate positions per workgroup tile (3 x 11.9 KiB; 3 workgroups per CU)
 #define QUEUE_DEPTH 16  // accepted-neighbour slots per lane between two SUM phases
 
 typedef float __attribute__((ext_vector_type(2))) f32x2;

@@ -30,6 +30,39 @@ __device__ __forceinline__ float2 neighbor_terms(const PairConsts& k, float rho_
    return make_float2(pj * rhoj_inv2, rhoj_inv * m_j * k.kernel3);
 }
 
+// (float)((double)n / den) for three numerators over one denominator.
+//
+// hipcc expands a correctly rounded f64 division to: rcp, two Newton steps on the reciprocal,
+// q = n*r, one residual step q' = fma(fma(-den, q, n), r, q) (plus v_div_scale / v_div_fixup,
+// which only act on operands far outside the range seen here).  The reciprocal part depends on
+// the denominator alone, so it is done once and each quotient keeps its own last two steps:
+// the same operations on the same values, hence the same bits as three separate divisions.
+// den is in [0.01, 0.01 + h]; a non-finite numerator (positions that already blew up) takes the
+// plain division so that infinities propagate exactly like on the CPU.
+__device__ __forceinline__ void div3_shared_den(float nx, float ny, float nz, double den,
+                                                float& qx, float& qy, float& qz)
+{
+   if (__builtin_isfinite(nx) && __builtin_isfinite(ny) && __builtin_isfinite(nz) &&
+       den >= 0.0078125 && den <= 1.0e6) {
+      double r = __builtin_amdgcn_rcp(den);
+      double e = __builtin_fma(-den, r, 1.0);
+      r = __builtin_fma(r, e, r);
+      e = __builtin_fma(-den, r, 1.0);
+      r = __builtin_fma(r, e, r);
+      const double dx = (double)nx, dy = (double)ny, dz = (double)nz;
+      double q = dx * r;
+      qx = (float)__builtin_fma(__builtin_fma(-den, q, dx), r, q);
+      q = dy * r;
+      qy = (float)__builtin_fma(__builtin_fma(-den, q, dy), r, q);
+      q = dz * r;
+      qz = (float)__builtin_fma(__builtin_fma(-den, q, dz), r, q);
+   } else {
+      qx = (float)((double)nx / den);
+      qy = (float)((double)ny / den);
+      qz = (float)((double)nz / den);
+   }
+}
+
 struct AccelState {
    float rhoi_inv, pi_div_rhoi2, visc_scale;
    float rx, ry, rz, vx, vy, vz;
@@ -63,9 +96,8 @@ __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, f
    const float rsz = UNIT_SCALE ? dz : dz * k.sim_scale;
    // float product, double add, double divide, narrowed to float (:854-856)
    const double den = (double)d + 0.01;
-   const float gx = (float)((double)(k.kernel2 * rsx) / den);
-   const float gy = (float)((double)(k.kernel2 * rsy) / den);
-   const float gz = (float)((double)(k.kernel2 * rsz) / den);
+   float gx, gy, gz;
+   div3_shared_den(k.kernel2 * rsx, k.kernel2 * rsy, k.kernel2 * rsz, den, gx, gy, gz);
 
    float center = (k.hscaled - d);
    center *= center;
