@@ -1,0 +1,41 @@
+// Headless driver for the drop-in: constructs the reference's `SPH` (body from sph_dropin.cpp,
+// header from the reference), calls step() a few times like `./sph r` would, and prints SHA-free
+// raw sums so the test can compare the host mirrors with the reference goldens.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define protected public
+#include "sph.h"
+#undef protected
+#include "particle.h"
+
+int main(int argc, char** argv)
+{
+   const int steps = argc > 1 ? atoi(argv[1]) : 1;
+   const char* out = argc > 2 ? argv[2] : "dropin_state.bin";
+   SPH sph;
+   for (int s = 0; s < steps; s++) sph.step();
+   Particle* p = sph.getParticles();
+   const int n = sph.getParticleCount();
+   FILE* f = fopen(out, "wb");
+   if (!f) return 2;
+   fwrite(&n, sizeof(int), 1, f);
+   fwrite(p->mPosition.data(), sizeof(float), 3 * n, f);
+   fwrite(p->mVelocity.data(), sizeof(float), 3 * n, f);
+   fwrite(p->mDensity.data(), sizeof(float), n, f);
+   fwrite(p->mAcceleration.data(), sizeof(float), 3 * n, f);
+   fwrite(p->mNeighborCount.data(), sizeof(int), n, f);
+   int gx, gy, gz;
+   sph.getGridCellCounts(gx, gy, gz);
+   long long occupied = 0, total = 0;
+   for (int c = 0; c < gx * gy * gz; c++) {
+      total += sph.getGrid()[c].count();
+      occupied += sph.getGrid()[c].count() > 0;
+   }
+   fwrite(&total, sizeof(long long), 1, f);
+   fclose(f);
+   printf("dropin: %d particles, %d steps, grid holds %lld in %lld voxels, KE %.9g PE %.9g\n", n,
+          steps, total, occupied, (double)sph.mKineticEnergyTotal, (double)sph.mPotentialEnergyTotal);
+   return 0;
+}

@@ -1,0 +1,232 @@
+// Drop-in body for the reference's solver class over the HIP C ABI.
+//
+// This file REPLACES the reference's src/sph.cpp in its CMake source list; src/sph.h,
+// src/particle.h, src/sphconfig.*, src/visualization.*, src/widget.*, src/main.cpp stay
+// untouched (moc still runs over the unchanged sph.h — no HIP type appears in it).  Link with
+// -lsph_hip.  It is compile-checked against the reference's header by
+// tests/test_integration_build.py wherever /root/reference exists.
+//
+// Every member keeps its meaning (reference src/sph.h:20-139):
+//   * the constructor derives the constants through sph_hip_params_default (same arithmetic as
+//     src/sph.cpp:46-98), builds the default scene and uploads it;
+//   * step() runs the five phases on the GPU, refreshes the host mirrors that the GUI reads
+//     without locks (Particle arrays, per-voxel QList sizes) and emits the same two signals;
+//   * the six setters store the value and hand the parameter block to the library, which
+//     applies it at the next phase.
+// The per-particle protected methods (findNeighbors(i, ...), computeDensity(i, ...), ...) have
+// no per-particle GPU meaning; they stay as no-ops because nothing outside step() calls them.
+#include "sph.h"
+
+#include "particle.h"
+
+#include <QElapsedTimer>
+#include <math.h>
+#include <stdlib.h>
+#include <sys/stat.h>
+
+#include <fstream>
+#include <iostream>
+
+#include "sph_hip.h"
+
+#ifndef M
+#define M 32
+#endif
+
+namespace {
+sph_hip_context* g_ctx = nullptr; // one solver per process, like the reference's single SPH object
+sph_hip_params g_prm;
+int g_mode = SPH_HIP_MODE_REF;    // SPH_HIP_MODE_FULL for complete neighbourhoods
+
+void check(int rc, const char* what)
+{
+   if (rc != SPH_HIP_OK) {
+      std::cerr << what << " failed: " << sph_hip_last_error(g_ctx) << std::endl;
+      abort(); // the reference has no error channel; a dead GPU path must not go unnoticed
+   }
+}
+} // namespace
+
+SPH::SPH()
+ : mParticleCount(0), mGridCellCount(0), mRho0(0.0f), mStopped(false), mPaused(false),
+   mKineticEnergyTotal(0.0f), mPotentialEnergyTotal(0.0f),
+   mAngularMomentumTotal(vec3(0.0f, 0.0f, 0.0f))
+{
+   if (getenv("SPH_HIP_FULL")) g_mode = SPH_HIP_MODE_FULL;
+   check(sph_hip_params_default(&g_prm, 0.1f, 32, 32, 32), "sph_hip_params_default");
+   // mirror the constants the GUI getters hand out
+   mSimulationScale = g_prm.sim_scale;
+   mSimulationScaleInverse = g_prm.sim_scale_inv;
+   mH = g_prm.h; mH2 = g_prm.h2; mHTimes2 = g_prm.htimes2; mHTimes2Inv = g_prm.htimes2inv;
+   mHScaled = g_prm.hscaled; mHScaled2 = g_prm.hscaled2; mHScaled6 = g_prm.hscaled6;
+   mHScaled9 = g_prm.hscaled9;
+   mParticleCount = M * 1024;
+   mGridCellsX = g_prm.cells_x; mGridCellsY = g_prm.cells_y; mGridCellsZ = g_prm.cells_z;
+   mGridCellCount = mGridCellsX * mGridCellsY * mGridCellsZ;
+   mCellSize = g_prm.cell_size;
+   mMaxX = g_prm.max_x; mMaxY = g_prm.max_y; mMaxZ = g_prm.max_z;
+   mTimeStep = g_prm.time_step;
+   totalSteps = (int)round(1.0f / mTimeStep);
+   mRho0 = g_prm.rho0; mStiffness = g_prm.stiffness;
+   mGravity = vec3(g_prm.gravity[0], g_prm.gravity[1], g_prm.gravity[2]);
+   mViscosityScalar = g_prm.viscosity; mDamping = g_prm.damping;
+   mGravConstant = g_prm.grav_const; mCentralMass = g_prm.central_mass;
+   for (int c = 0; c < 3; c++) mCentralPos[c] = g_prm.central_pos[c];
+   mSoftening = g_prm.softening;
+   mCflLimit = g_prm.cfl_limit; mCflLimit2 = g_prm.cfl_limit2;
+   mKernel1Scaled = g_prm.kernel1; mKernel2Scaled = g_prm.kernel2; mKernel3Scaled = g_prm.kernel3;
+   mExamineCount = g_prm.examine_count;
+
+   mSrcParticles = new Particle(mParticleCount);
+   for (int i = 0; i < mParticleCount; i++) mSrcParticles->mMass[i] = 1.0f;
+   mVoxelIds = new int[mParticleCount];
+   mVoxelCoords = new vec3i[mParticleCount];
+   mGrid = new QList<uint32_t>[mGridCellCount];
+   mNeighbors = nullptr;               // lists live on the device
+   mNeighborDistancesScaled = nullptr;
+
+   initParticlePolitionsSphere();
+   check(sph_hip_create(&g_ctx, &g_prm, mParticleCount, g_mode, 0), "sph_hip_create");
+   check(sph_hip_upload(g_ctx, mParticleCount, mSrcParticles->mPosition.data(),
+                        mSrcParticles->mVelocity.data(), mSrcParticles->mMass.data()),
+         "sph_hip_upload");
+}
+
+SPH::~SPH()
+{
+   stopSimulation();
+   quit();
+   wait();
+   sph_hip_destroy(g_ctx);
+   g_ctx = nullptr;
+}
+
+bool SPH::isStopped() const { mMutex.lock(); bool s = mStopped; mMutex.unlock(); return s; }
+bool SPH::isPaused() const { mMutex.lock(); bool p = mPaused; mMutex.unlock(); return p; }
+void SPH::pauseResume() { mMutex.lock(); mPaused = !mPaused; mMutex.unlock(); }
+void SPH::stopSimulation() { mMutex.lock(); mStopped = true; mMutex.unlock(); }
+
+void SPH::run()
+{
+   int stepCount = 0;
+   mkdir("out", 0777);
+   std::ofstream energy("out/energy.txt"), timing("out/timing.txt");
+   energy << "Step, Kinetic Energy, Potential Energy, Total Energy" << std::endl;
+   timing << "Step, Voxelize, Find Neighbors, Compute Density, Compute Pressure, "
+             "Compute Acceleration, Integrate" << std::endl;
+   while (!isStopped() && stepCount <= totalSteps) {
+      if (isPaused()) continue;
+      step();
+      energy << stepCount << ", " << mKineticEnergyTotal << ", " << mPotentialEnergyTotal << ", "
+             << mKineticEnergyTotal + mPotentialEnergyTotal << std::endl;
+      timing << stepCount << ", " << timeVoxelize << ", " << timeFindNeighbors << ", "
+             << timeComputeDensity << ", " << timeComputePressure << ", " << timeComputeAcceleration
+             << ", " << timeIntegrate << std::endl;
+      stepCount++;
+   }
+}
+
+void SPH::step()
+{
+   // parameters edited by the GUI since the last step (SphConfig::writeValuesToSimulation)
+   check(sph_hip_set_params(g_ctx, &g_prm), "sph_hip_set_params");
+   check(sph_hip_step(g_ctx), "sph_hip_step");
+
+   float ms[6];
+   check(sph_hip_get_timings(g_ctx, ms), "sph_hip_get_timings");
+   timeVoxelize = (int)ms[0]; timeFindNeighbors = (int)ms[1]; timeComputeDensity = (int)ms[2];
+   timeComputePressure = (int)ms[3]; timeComputeAcceleration = (int)ms[4];
+   timeIntegrate = (int)ms[5];
+   check(sph_hip_get_energy(g_ctx, &mKineticEnergyTotal, &mPotentialEnergyTotal),
+         "sph_hip_get_energy");
+
+   // host mirrors read by Visualization / SphConfig (src/visualization.cpp:144-158, 178-193)
+   Particle* p = mSrcParticles;
+   check(sph_hip_download(g_ctx, p->mPosition.data(), p->mVelocity.data(), p->mDensity.data(),
+                          p->mAcceleration.data(), p->mNeighborCount.data()), "sph_hip_download");
+   if (g_mode == SPH_HIP_MODE_REF) {
+      static std::vector<int32_t> counts;
+      counts.resize(mGridCellCount);
+      check(sph_hip_download_grid_counts(g_ctx, counts.data()), "sph_hip_download_grid_counts");
+      for (int c = 0; c < mGridCellCount; c++) {   // only count() is ever read from these lists
+         QList<uint32_t>& l = mGrid[c];
+         while (l.size() > counts[c]) l.removeLast();
+         while (l.size() < counts[c]) l.append(0u);
+      }
+   }
+   emit updateElapsed(timeVoxelize, timeFindNeighbors, timeComputeDensity, timeComputePressure,
+                      timeComputeAcceleration, timeIntegrate);
+   emit stepFinished();
+}
+
+// ---- default scene: same sequence of rand() calls and float/double arithmetic as the
+// ---- reference's initParticlePolitionsSphere (src/sph.cpp:361-425)
+void SPH::initParticlePolitionsSphere()
+{
+   srand(42);
+   const float cx = mMaxX * 0.5f, cy = mMaxY * 0.5f, cz = mMaxZ * 0.5f, radius = 2.0f;
+   for (int i = 0; i < mParticleCount; i++) {
+      float x, y, z, dist;
+      do {
+         x = rand() / (float)RAND_MAX; y = rand() / (float)RAND_MAX; z = rand() / (float)RAND_MAX;
+         x *= mGridCellsX * mHTimes2; y *= mGridCellsY * mHTimes2; z *= mGridCellsZ * mHTimes2;
+         if (x == (float)mGridCellsX) x -= 0.00001f;
+         if (y == (float)mGridCellsY) y -= 0.00001f;
+         if (z == (float)mGridCellsZ) z -= 0.00001f;
+         dist = sqrtf((x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz));
+      } while (dist > radius);
+      mSrcParticles->mPosition[3 * i] = x;
+      mSrcParticles->mPosition[3 * i + 1] = y;
+      mSrcParticles->mPosition[3 * i + 2] = z;
+      const float phi = atan2f(z - cz, x - cx);
+      const double amp = 20.0f * pow((double)dist + (double)mHScaled * 0.5, -0.5);
+      mSrcParticles->mVelocity[3 * i] = (float)(amp * -sinf(phi));
+      mSrcParticles->mVelocity[3 * i + 2] = (float)(amp * cosf(phi));
+      mSrcParticles->mVelocity[3 * i + 1] = ((rand() / (float)RAND_MAX) * 0.5f) - 0.25f;
+   }
+}
+void SPH::initParticlePositionsRandom() {}
+
+// ---- per-particle pipeline members: subsumed by sph_hip_step() ---------------------------------
+void SPH::clearGrid() {}
+void SPH::voxelizeParticles() { check(sph_hip_voxelize(g_ctx), "sph_hip_voxelize"); }
+void SPH::findNeighbors(int, uint32_t*, int, int, int, float*) {}
+void SPH::computeDensity(int, uint32_t*, float*) {}
+void SPH::computePressure(int) {}
+void SPH::computeAcceleration(int, uint32_t*, float*) {}
+void SPH::integrate(int) {}
+int SPH::evaluateNeighbor(int, int) { return 0; }
+int SPH::computeVoxelId(int x, int y, int z) { return (z * mGridCellsY + y) * mGridCellsX + x; }
+void SPH::applyBoundary(vec3, float, vec3*, float, vec3, vec3*) {}
+void SPH::handleBoundaryConditions(vec3, vec3*, float, vec3*) {}
+void SPH::clearNeighbors() {}
+void SPH::memClear32(void*, int) {}
+
+// ---- getters / setters (reference src/sph.cpp:1172-1289) -----------------------------------------
+float SPH::getCellSize() const { return mCellSize; }
+Particle* SPH::getParticles() { return mSrcParticles; }
+int SPH::getParticleCount() const { return mParticleCount; }
+void SPH::getGridCellCounts(int& x, int& y, int& z) { x = mGridCellsX; y = mGridCellsY; z = mGridCellsZ; }
+void SPH::getParticleBounds(float& x, float& y, float& z) { x = mMaxX; y = mMaxY; z = mMaxZ; }
+float SPH::getInteractionRadius2() const { return mHScaled2; }
+QList<uint32_t>* SPH::getGrid() { return mGrid; }
+vec3 SPH::getGravity() const { return mGravity; }
+void SPH::setGravity(const vec3& g)
+{
+   mGravity = g;
+   g_prm.gravity[0] = g.x; g_prm.gravity[1] = g.y; g_prm.gravity[2] = g.z;
+}
+float SPH::getCflLimit() const { return mCflLimit; }
+void SPH::setCflLimit(float v)
+{
+   mCflLimit = v; mCflLimit2 = v * v;
+   g_prm.cfl_limit = mCflLimit; g_prm.cfl_limit2 = mCflLimit2;
+}
+float SPH::getDamping() const { return mDamping; }
+void SPH::setDamping(float v) { mDamping = v; g_prm.damping = v; }
+float SPH::getTimeStep() const { return mTimeStep; }
+void SPH::setTimeStep(float v) { mTimeStep = v; g_prm.time_step = v; }
+float SPH::getViscosityScalar() const { return mViscosityScalar; }
+void SPH::setViscosityScalar(float v) { mViscosityScalar = v; g_prm.viscosity = v; }
+float SPH::getStiffness() const { return mStiffness; }
+void SPH::setStiffness(float v) { mStiffness = v; g_prm.stiffness = v; }
