@@ -67,6 +67,19 @@ def cpu_baseline(n_sample, steps, n_total):
     }
 
 
+def measured_traffic(n):
+    """HBM bytes per density+acceleration launch pair from the committed PMC passes
+    (profiles/r1_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    FETCH doubled as the gfx950 guide prescribes).  None when no profile matches the workload."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+        if prof.get("particles") == n:
+            return prof["density_plus_acceleration_hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def run_single(args, S, scenes, torch, local_rank):
     """N = 1: one context holds the whole grid."""
     n = args.particles
@@ -215,7 +228,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(n) if world == 1 else None,
+                "traffic_unit": "bytes per launch pair (profiles/r1_hbm_traffic.json)",
                 "bytes_per_particle": DENSITY_FORCE_BYTES,
                 "particles_per_launch": n_rank,
                 "ms_per_launch_pair": df_ms,
