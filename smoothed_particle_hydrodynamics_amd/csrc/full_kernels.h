@@ -89,8 +89,10 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
              int tile_cap)
 {
    if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
-   const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= meta[META_OWN_END]) return;
+   // same workgroup -> particle mapping as the tiled kernels (from the density range); the
+   // acceleration is only needed for owned particles
+   const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) return;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);

@@ -27,7 +27,14 @@
 
 #define TILE_THREADS 256
 #define TILE_CAP 3008   // candidate positions per workgroup tile (3 x 11.9 KiB; 3 workgroups per CU)
-#define QUEUE_DEPTH 16  // accepted-neighbour slots per lane between two SUM phases
+#define QUEUE_DEPTH 32  // accepted-neighbour slots per lane between two SUM phases
+// Neighbour lists handed from the density pass to the acceleration pass: per workgroup
+// NLIST_CAP rows of 256 u16 queue entries (row j = every lane's j-th accepted neighbour, so a
+// wave reads/writes 128 contiguous bytes).  Only rows in use are ever touched.
+#define NLIST_CAP 96
+// queue entry: segment id << 12 | tile index (TILE_CAP + 32 <= 4096)
+#define QUEUE_TBITS 12
+#define QUEUE_TMASK 0xfffu
 
 typedef float __attribute__((ext_vector_type(2))) f32x2;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
@@ -38,6 +45,7 @@ __device__ __forceinline__ f32x4 lds_read4(const float* base, int i)
    return *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + i, 16));
 }
 
+static_assert(TILE_CAP + 32 <= (1 << QUEUE_TBITS), "tile index must fit the queue entry");
 #define TILE_ROUNDS ((TILE_CAP + TILE_THREADS - 1) / TILE_THREADS)
 
 // Per-workgroup tile layout, computed by k_tile_desc before the sums run.
@@ -52,7 +60,7 @@ struct TileLds {
    __attribute__((aligned(16))) float x[TILE_CAP + 32];
    __attribute__((aligned(16))) float y[TILE_CAP + 32];
    __attribute__((aligned(16))) float z[TILE_CAP + 32];
-   uint32_t queue[QUEUE_DEPTH * TILE_THREADS];
+   uint16_t queue[QUEUE_DEPTH * TILE_THREADS];
    TileDesc desc;
 };
 
@@ -158,37 +166,52 @@ __device__ __forceinline__ f32x2 dist2_pair(f32x2 px, f32x2 py, f32x2 pz, f32x2 
 template <bool UNIT_SCALE, bool UNIFORM_MASS, int PASS>
 struct TiledSum;
 
+// What the SUM phase needs of one queued neighbour.
+struct Staged {
+   uint32_t entry;
+   float x, y, z, m;
+   float4 v;
+   float2 bc;
+};
+
 // ---- density -------------------------------------------------------------------------------
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
 struct TiledSum<UNIT_SCALE, UNIFORM_MASS, 0> {
    float density = 0.0f;
    int count = 0;
-   __device__ __forceinline__ void drain(const PairConsts& k, const TileLds& L, int tid, int qn,
-                                         const float4& pi, uint32_t self_entry,
-                                         const float4* __restrict__ posm,
+   uint16_t* nlist = nullptr;  // this lane's column of the workgroup's list block
+   int overflow = 0;
+
+   __device__ __forceinline__ void stage(Staged& s, const TileLds& L, int tid, int j,
+                                         const float4& pi, const float4* __restrict__ posm,
                                          const float4* __restrict__ velp,
-                                         const float2* __restrict__ aux)
+                                         const float2* __restrict__ aux) const
    {
-      for (int j = 0; __any(j < qn); ++j) {
-         if (j < qn) {
-            const uint32_t entry = L.queue[j * TILE_THREADS + tid];
+      s.entry = L.queue[j * TILE_THREADS + tid];
+      const int t = (int)(s.entry & QUEUE_TMASK);
+      s.x = L.x[t];
+      s.y = L.y[t];
+      s.z = L.z[t];
+      s.m = pi.w;
+      if (!UNIFORM_MASS) s.m = posm[t - L.desc.D[s.entry >> QUEUE_TBITS]].w;
+   }
+
+   __device__ __forceinline__ void pair(const PairConsts& k, const Staged& s, const float4& pi,
+                                        uint32_t self_entry)
+   {
 #if defined(SPH_ABLATE) && SPH_ABLATE == 1
-            if (entry != self_entry) count++;
-            if (false) {
-#else
-            if (entry != self_entry) {
+      if (s.entry != self_entry) count++;
+      return;
 #endif
-               const int t = (int)(entry & 0xffffu);
-               float mj = pi.w;
-               if (!UNIFORM_MASS) mj = posm[t - L.desc.D[entry >> 16]].w;
-               float dx, dy, dz;
-               const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-               float d = sqrtf(d2);
-               if (!UNIT_SCALE) d *= k.sim_scale;
-               density_accumulate(k, mj, d, density);
-               count++;
-            }
-         }
+      if (s.entry != self_entry) {
+         float dx, dy, dz;
+         const float d2 = dist2(pi.x, pi.y, pi.z, s.x, s.y, s.z, dx, dy, dz);
+         float d = sqrtf(d2);
+         if (!UNIT_SCALE) d *= k.sim_scale;
+         density_accumulate(k, s.m, d, density);
+         if (count < NLIST_CAP) nlist[count * TILE_THREADS] = (uint16_t)s.entry;
+         else overflow = 1;
+         count++;
       }
    }
 };
@@ -197,37 +220,67 @@ struct TiledSum<UNIT_SCALE, UNIFORM_MASS, 0> {
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
 struct TiledSum<UNIT_SCALE, UNIFORM_MASS, 1> {
    AccelState s;
-   __device__ __forceinline__ void drain(const PairConsts& k, const TileLds& L, int tid, int qn,
-                                         const float4& pi, uint32_t self_entry,
-                                         const float4* __restrict__ posm,
+
+   __device__ __forceinline__ void stage(Staged& g, const TileLds& L, int tid, int j,
+                                         const float4& pi, const float4* __restrict__ posm,
                                          const float4* __restrict__ velp,
-                                         const float2* __restrict__ aux)
+                                         const float2* __restrict__ aux) const
    {
-      for (int j = 0; __any(j < qn); ++j) {
-         if (j < qn) {
-            const uint32_t entry = L.queue[j * TILE_THREADS + tid];
+      stage_entry(g, L.queue[j * TILE_THREADS + tid], L, pi, posm, velp, aux);
+   }
+
+   __device__ __forceinline__ void stage_entry(Staged& g, uint32_t entry, const TileLds& L,
+                                               const float4& pi, const float4* __restrict__ posm,
+                                               const float4* __restrict__ velp,
+                                               const float2* __restrict__ aux) const
+   {
+      g.entry = entry;
+      const int t = (int)(g.entry & QUEUE_TMASK);
+      const int q = t - L.desc.D[g.entry >> QUEUE_TBITS];
+      g.v = velp[q];
+      g.bc = aux[q];
+      g.m = pi.w;
+      if (!UNIFORM_MASS) g.m = posm[q].w;
+      g.x = L.x[t];
+      g.y = L.y[t];
+      g.z = L.z[t];
+   }
+
+   __device__ __forceinline__ void pair(const PairConsts& k, const Staged& g, const float4& pi,
+                                        uint32_t self_entry)
+   {
 #if defined(SPH_ABLATE) && SPH_ABLATE == 1
-            if (entry != self_entry) s.pgx += __uint_as_float(entry);
-            if (false) {
-#else
-            if (entry != self_entry) {
+      if (g.entry != self_entry) s.pgx += __uint_as_float(g.entry);
+      return;
 #endif
-               const int t = (int)(entry & 0xffffu);
-               const int q = t - L.desc.D[entry >> 16];
-               const float4 vj = velp[q];
-               const float2 bc = aux[q];
-               float mj = pi.w;
-               if (!UNIFORM_MASS) mj = posm[q].w;
-               float dx, dy, dz;
-               const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-               float d = sqrtf(d2);
-               if (!UNIT_SCALE) d *= k.sim_scale;
-               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, bc.x, bc.y);
-            }
-         }
+      if (g.entry != self_entry) {
+         float dx, dy, dz;
+         const float d2 = dist2(pi.x, pi.y, pi.z, g.x, g.y, g.z, dx, dy, dz);
+         float d = sqrtf(d2);
+         if (!UNIT_SCALE) d *= k.sim_scale;
+         accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, g.m, g.v.x, g.v.y, g.v.z, g.bc.x, g.bc.y);
       }
    }
 };
+
+// SUM phase: every lane walks its queue [0, qn) in order.  (Fetching iteration j+1's operands
+// ahead of iteration j's arithmetic was measured slower: the extra register copies and branch
+// cost more than the latency they hide at 3 waves per SIMD.)
+template <class Sum>
+__device__ __forceinline__ void drain_queue(Sum& sum, const PairConsts& k, const TileLds& L,
+                                            int tid, int qn, const float4& pi,
+                                            uint32_t self_entry, const float4* __restrict__ posm,
+                                            const float4* __restrict__ velp,
+                                            const float2* __restrict__ aux)
+{
+   for (int j = 0; __any(j < qn); ++j) {
+      if (j < qn) {
+         Staged s;
+         sum.stage(s, L, tid, j, pi, posm, velp, aux);
+         sum.pair(k, s, pi, self_entry);
+      }
+   }
+}
 
 // TEST step: eight consecutive, 32-byte aligned tile slots t..t+7 -> 8 acceptance bits.
 // Six independent ds_read_b128 and branch-free packed math; slots outside the lane's range
@@ -264,21 +317,30 @@ k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
              PairConsts k, float* __restrict__ rho_out, float2* __restrict__ aux_out,
              int32_t* __restrict__ ncount, float4* __restrict__ acc,
-             const TileDesc* __restrict__ desc)
+             const TileDesc* __restrict__ desc, uint16_t* __restrict__ nlist,
+             uint32_t* __restrict__ nlist_overflow)
 {
    __shared__ __attribute__((aligned(16))) TileLds L;
+   __shared__ int list_overflow;
 
-   // density runs over planes [lo-1, hi+1) (the owned particles' neighbours need it), the
-   // acceleration over the owned planes only; both are contiguous ranges of the sorted state
-   const int begin = meta[PASS == 0 ? META_SUM_BEGIN : META_OWN_BEGIN];
-   const int end = meta[PASS == 0 ? META_SUM_END : META_OWN_END];
+   // Both passes tile the range whose density is needed, planes [lo-1, hi+1): the same tiling
+   // lets the acceleration pass reuse the density pass's neighbour lists.  The acceleration
+   // is only computed for the owned planes [lo, hi), a sub-range.
+   const int begin = meta[META_SUM_BEGIN];
+   const int end = meta[META_SUM_END];
    const int tid = threadIdx.x;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
    if (p0 >= end) return;
    const int p = p0 + tid;
-   const bool live = p < end;
+   bool live = p < end;
+   if (PASS == 1) {
+      const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+      if (p0 + TILE_THREADS <= ob || p0 >= oe) return;  // a workgroup of ghosts only
+      live = live && p >= ob && p < oe;
+   }
    tile_load(posm, desc, L);
    if (L.desc.total > TILE_CAP) return;  // tile does not fit: the untiled kernel redoes this workgroup
+   uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
 
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
    RowRanges r;
@@ -292,17 +354,38 @@ k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
       row_ranges(g, cell_start, cx, cy, cz, r);
 #endif
    }
-   const uint32_t self_entry = (4u << 16) | (uint32_t)(p + L.desc.D[4]);
+   const uint32_t self_entry = (4u << QUEUE_TBITS) | (uint32_t)(p + L.desc.D[4]);
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
 
    TiledSum<UNIT_SCALE, UNIFORM_MASS, PASS> sum;
-   if constexpr (PASS == 1) accel_begin(k, sum.s, pi, live ? velp[p] : pi, live ? rho_in[p] : 0.0f);
+   if constexpr (PASS == 0) {
+      sum.nlist = my_list;
+      if (tid == 0) list_overflow = 0;
+      __syncthreads();
+   }
+   if constexpr (PASS == 1) {
+      accel_begin(k, sum.s, pi, live ? velp[p] : pi, live ? rho_in[p] : 0.0f);
+      if (!nlist_overflow[blockIdx.x]) {
+         // LIST path: the density pass left every lane's accepted neighbours (self excluded),
+         // in canonical order, in this workgroup's list block
+         const int cnt = live ? ncount[p] : 0;
+         for (int j = 0; __any(j < cnt); ++j) {
+            if (j < cnt) {
+               Staged g;
+               sum.stage_entry(g, my_list[j * TILE_THREADS], L, pi, posm, velp, aux_in);
+               sum.pair(k, g, pi, 0xffffffffu);
+            }
+         }
+         if (live) acc[p] = accel_end<UNIT_SCALE>(k, sum.s);
+         return;
+      }
+   }
 
    int qn = 0;
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = L.desc.D[kk];
-      const uint32_t kbits = (uint32_t)kk << 16;
+      const uint32_t kbits = (uint32_t)kk << QUEUE_TBITS;
       const int ts = (int)r.s[kk] + D;
       const int te = (int)r.e[kk] + D;
       // chunks of 32 tile slots starting at an 8-aligned slot; one acceptance bit per slot
@@ -327,18 +410,23 @@ k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
             if (mask != 0u && qn < QUEUE_DEPTH) {
                const int bit = __builtin_ctz(mask);
                mask &= mask - 1u;
-               L.queue[qn * TILE_THREADS + tid] = kbits | (uint32_t)(t0 + bit);
+               L.queue[qn * TILE_THREADS + tid] = (uint16_t)(kbits | (uint32_t)(t0 + bit));
                qn++;
             }
             if (__any(qn == QUEUE_DEPTH)) {
-               sum.drain(k, L, tid, qn, pi, self_entry, posm, velp, aux_in);
+               drain_queue(sum, k, L, tid, qn, pi, self_entry, posm, velp, aux_in);
                qn = 0;
             }
          }
       }
    }
-   sum.drain(k, L, tid, qn, pi, self_entry, posm, velp, aux_in);
+   drain_queue(sum, k, L, tid, qn, pi, self_entry, posm, velp, aux_in);
 
+   if constexpr (PASS == 0) {
+      if (sum.overflow) list_overflow = 1;
+      __syncthreads();
+      if (tid == 0) nlist_overflow[blockIdx.x] = (uint32_t)list_overflow;
+   }
    if (live) {
       if constexpr (PASS == 0) {
          rho_out[p] = sum.density;

@@ -66,7 +66,8 @@ void free_all(sph_hip_context* ctx)
    }
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
                    ctx->scan_part, ctx->rho, ctx->aux, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
-                   ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta};
+                   ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta, ctx->nlist,
+                   ctx->nlist_overflow};
    for (void* q : ptrs)
       if (q) (void)hipFree(q);
    if (ctx->ev) {
@@ -158,7 +159,7 @@ void launch_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts&
    hipLaunchKernelGGL((k_full_tiled<U, M, PASS>), dim3(blocks), dim3(TILE_THREADS), 0,           \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux, \
                       ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->aux, ctx->ncount, \
-                      ctx->acc, ctx->tile_desc)
+                      ctx->acc, ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
    if (unit && ctx->uniform_mass) SPH_TILED(true, true);
    else if (unit) SPH_TILED(true, false);
    else if (ctx->uniform_mass) SPH_TILED(false, true);
@@ -217,11 +218,8 @@ int launch_accel(sph_hip_context* ctx)
       const bool unit = unit_scale(ctx->prm);
       const int* flags = nullptr;
       if (ctx->use_tiled) {
-         // workgroups now tile the OWNED range (the density pass tiled a wider one)
+         // same tiling (and tile descriptors) as the density pass of this step
          flags = &ctx->tile_desc->total;
-         hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_OWN_BEGIN,
-                            ctx->grid, blocks, ctx->tile_desc);
          launch_tiled<1>(ctx, unit, blocks, k);
       }
 #if defined(SPH_ABLATE) && SPH_ABLATE == 6
@@ -433,6 +431,8 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    if (mode == SPH_HIP_MODE_FULL) {
       CREATE_TRY(dev_alloc(&ctx->aux, cap));
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
+      CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_CAP * TILE_THREADS));
+      CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
       if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
    } else {
       CREATE_TRY(dev_alloc(&ctx->order, cap));
