@@ -42,13 +42,15 @@ __device__ __forceinline__ void row_ranges(const CellGrid& g, const uint32_t* __
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
 k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
-               const int32_t* __restrict__ meta, CellGrid g, PairConsts k, float* __restrict__ rho,
-               float2* __restrict__ aux, int32_t* __restrict__ ncount,
-               const int* __restrict__ tile_total, int tile_cap)
+               const float4* __restrict__ velp, const int32_t* __restrict__ meta, CellGrid g,
+               PairConsts k, float* __restrict__ rho, float4* __restrict__ velB,
+               float* __restrict__ auxc, int32_t* __restrict__ ncount,
+               const int* __restrict__ tile_total, int tile_cap,
+               const uint32_t* __restrict__ list_overflow)
 {
-   // as the fallback of the tiled kernel: run only the workgroups whose tile overflowed
-   // (tile_total points at TileDesc::total of workgroup 0, stride 20 ints)
-   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
+   // as the fallback of the tiled kernel: run only the workgroups whose tile or neighbour lists
+   // overflowed (tile_total points at TileDesc::total of workgroup 0, stride 20 ints)
+   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap && !list_overflow[blockIdx.x]) return;
    const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= meta[META_SUM_END]) return;
    const float4 pi = posm[p];
@@ -75,20 +77,24 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
       }
    }
    rho[p] = density;
-   aux[p] = neighbor_terms(k, density, pi.w);
+   const float2 bc = neighbor_terms(k, density, pi.w);
+   const float4 v = velp[p];
+   velB[p] = make_float4(v.x, v.y, v.z, bc.x);
+   auxc[p] = bc.y;
    ncount[p] = count;
 }
 
 // ---- acceleration, untiled ------------------------------------------------------------------------
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
-k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
-             const float* __restrict__ rho, const float2* __restrict__ aux,
+k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
+             const float* __restrict__ rho, const float* __restrict__ auxc,
              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
              PairConsts k, float4* __restrict__ acc, const int* __restrict__ tile_total,
-             int tile_cap)
+             int tile_cap, const uint32_t* __restrict__ list_overflow)
 {
-   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap) return;
+   // fallback of the tiled list kernel: workgroups whose tile or neighbour lists overflowed
+   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap && !list_overflow[blockIdx.x]) return;
    // same workgroup -> particle mapping as the tiled kernels (from the density range); the
    // acceleration is only needed for owned particles
    const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,7 +106,7 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
    row_ranges(g, cell_start, cx, cy, cz, r);
 
    AccelState s;
-   accel_begin(k, s, pi, velp[p], rho[p]);
+   accel_begin(k, s, pi, velB[p], rho[p]);
 #pragma unroll
    for (int row = 0; row < 9; row++) {
       for (uint32_t q = r.s[row]; q < r.e[row]; q++) {
@@ -111,9 +117,8 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
          if (d2 < k.h2) {
             float d = sqrtf(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
-            const float4 vj = velp[q];
-            const float2 bc = aux[q];
-            accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w, vj.x, vj.y, vj.z, bc.x, bc.y);
+            const float4 vj = velB[q];
+            accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w, vj.x, vj.y, vj.z, vj.w, auxc[q]);
          }
       }
    }

@@ -27,7 +27,6 @@
 
 #define TILE_THREADS 256
 #define TILE_CAP 3008   // candidate positions per workgroup tile (3 x 11.9 KiB; 3 workgroups per CU)
-#define QUEUE_DEPTH 32  // accepted-neighbour slots per lane between two SUM phases
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
 // NLIST_CAP rows of 256 u16 queue entries (row j = every lane's j-th accepted neighbour, so a
 // wave reads/writes 128 contiguous bytes).  Only rows in use are ever touched.
@@ -60,7 +59,6 @@ struct TileLds {
    __attribute__((aligned(16))) float x[TILE_CAP + 32];
    __attribute__((aligned(16))) float y[TILE_CAP + 32];
    __attribute__((aligned(16))) float z[TILE_CAP + 32];
-   uint16_t queue[QUEUE_DEPTH * TILE_THREADS];
    TileDesc desc;
 };
 
@@ -163,125 +161,6 @@ __device__ __forceinline__ f32x2 dist2_pair(f32x2 px, f32x2 py, f32x2 pz, f32x2 
    return dx * dx + dy * dy + dz * dz;
 }
 
-template <bool UNIT_SCALE, bool UNIFORM_MASS, int PASS>
-struct TiledSum;
-
-// What the SUM phase needs of one queued neighbour.
-struct Staged {
-   uint32_t entry;
-   float x, y, z, m;
-   float4 v;
-   float2 bc;
-};
-
-// ---- density -------------------------------------------------------------------------------
-template <bool UNIT_SCALE, bool UNIFORM_MASS>
-struct TiledSum<UNIT_SCALE, UNIFORM_MASS, 0> {
-   float density = 0.0f;
-   int count = 0;
-   uint16_t* nlist = nullptr;  // this lane's column of the workgroup's list block
-   int overflow = 0;
-
-   __device__ __forceinline__ void stage(Staged& s, const TileLds& L, int tid, int j,
-                                         const float4& pi, const float4* __restrict__ posm,
-                                         const float4* __restrict__ velp,
-                                         const float2* __restrict__ aux) const
-   {
-      s.entry = L.queue[j * TILE_THREADS + tid];
-      const int t = (int)(s.entry & QUEUE_TMASK);
-      s.x = L.x[t];
-      s.y = L.y[t];
-      s.z = L.z[t];
-      s.m = pi.w;
-      if (!UNIFORM_MASS) s.m = posm[t - L.desc.D[s.entry >> QUEUE_TBITS]].w;
-   }
-
-   __device__ __forceinline__ void pair(const PairConsts& k, const Staged& s, const float4& pi,
-                                        uint32_t self_entry)
-   {
-#if defined(SPH_ABLATE) && SPH_ABLATE == 1
-      if (s.entry != self_entry) count++;
-      return;
-#endif
-      if (s.entry != self_entry) {
-         float dx, dy, dz;
-         const float d2 = dist2(pi.x, pi.y, pi.z, s.x, s.y, s.z, dx, dy, dz);
-         float d = sqrtf(d2);
-         if (!UNIT_SCALE) d *= k.sim_scale;
-         density_accumulate(k, s.m, d, density);
-         if (count < NLIST_CAP) nlist[count * TILE_THREADS] = (uint16_t)s.entry;
-         else overflow = 1;
-         count++;
-      }
-   }
-};
-
-// ---- acceleration ----------------------------------------------------------------------------
-template <bool UNIT_SCALE, bool UNIFORM_MASS>
-struct TiledSum<UNIT_SCALE, UNIFORM_MASS, 1> {
-   AccelState s;
-
-   __device__ __forceinline__ void stage(Staged& g, const TileLds& L, int tid, int j,
-                                         const float4& pi, const float4* __restrict__ posm,
-                                         const float4* __restrict__ velp,
-                                         const float2* __restrict__ aux) const
-   {
-      stage_entry(g, L.queue[j * TILE_THREADS + tid], L, pi, posm, velp, aux);
-   }
-
-   __device__ __forceinline__ void stage_entry(Staged& g, uint32_t entry, const TileLds& L,
-                                               const float4& pi, const float4* __restrict__ posm,
-                                               const float4* __restrict__ velp,
-                                               const float2* __restrict__ aux) const
-   {
-      g.entry = entry;
-      const int t = (int)(g.entry & QUEUE_TMASK);
-      const int q = t - L.desc.D[g.entry >> QUEUE_TBITS];
-      g.v = velp[q];
-      g.bc = aux[q];
-      g.m = pi.w;
-      if (!UNIFORM_MASS) g.m = posm[q].w;
-      g.x = L.x[t];
-      g.y = L.y[t];
-      g.z = L.z[t];
-   }
-
-   __device__ __forceinline__ void pair(const PairConsts& k, const Staged& g, const float4& pi,
-                                        uint32_t self_entry)
-   {
-#if defined(SPH_ABLATE) && SPH_ABLATE == 1
-      if (g.entry != self_entry) s.pgx += __uint_as_float(g.entry);
-      return;
-#endif
-      if (g.entry != self_entry) {
-         float dx, dy, dz;
-         const float d2 = dist2(pi.x, pi.y, pi.z, g.x, g.y, g.z, dx, dy, dz);
-         float d = sqrtf(d2);
-         if (!UNIT_SCALE) d *= k.sim_scale;
-         accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, g.m, g.v.x, g.v.y, g.v.z, g.bc.x, g.bc.y);
-      }
-   }
-};
-
-// SUM phase: every lane walks its queue [0, qn) in order.  (Fetching iteration j+1's operands
-// ahead of iteration j's arithmetic was measured slower: the extra register copies and branch
-// cost more than the latency they hide at 3 waves per SIMD.)
-template <class Sum>
-__device__ __forceinline__ void drain_queue(Sum& sum, const PairConsts& k, const TileLds& L,
-                                            int tid, int qn, const float4& pi,
-                                            uint32_t self_entry, const float4* __restrict__ posm,
-                                            const float4* __restrict__ velp,
-                                            const float2* __restrict__ aux)
-{
-   for (int j = 0; __any(j < qn); ++j) {
-      if (j < qn) {
-         Staged s;
-         sum.stage(s, L, tid, j, pi, posm, velp, aux);
-         sum.pair(k, s, pi, self_entry);
-      }
-   }
-}
-
 // TEST step: eight consecutive, 32-byte aligned tile slots t..t+7 -> 8 acceptance bits.
 // Six independent ds_read_b128 and branch-free packed math; slots outside the lane's range
 // are masked by the caller.
@@ -310,37 +189,33 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
    return m;
 }
 
-template <bool UNIT_SCALE, bool UNIFORM_MASS, int PASS>
-__global__ void __launch_bounds__(TILE_THREADS, 3)
-k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
-             const float* __restrict__ rho_in, const float2* __restrict__ aux_in,
-             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
-             PairConsts k, float* __restrict__ rho_out, float2* __restrict__ aux_out,
-             int32_t* __restrict__ ncount, float4* __restrict__ acc,
-             const TileDesc* __restrict__ desc, uint16_t* __restrict__ nlist,
-             uint32_t* __restrict__ nlist_overflow)
+// ---- density pass: TILE + TEST (-> neighbour list) + SUM (<- neighbour list) --------------------
+// TEST appends every accepted neighbour (self excluded), in canonical order, to the lane's
+// column of the workgroup's list block in global memory; SUM then walks that list once.  The
+// list doubles as the input of the acceleration pass.  A workgroup in which some particle has
+// more than NLIST_CAP neighbours gives up (flag) and is redone by the untiled kernel.
+template <bool UNIT_SCALE, bool UNIFORM_MASS>
+__global__ void __launch_bounds__(TILE_THREADS, 4)
+k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
+                     const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
+                     CellGrid g, PairConsts k, float* __restrict__ rho_out,
+                     float4* __restrict__ velB_out, float* __restrict__ auxc_out,
+                     int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
+                     uint16_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow)
 {
    __shared__ __attribute__((aligned(16))) TileLds L;
    __shared__ int list_overflow;
 
-   // Both passes tile the range whose density is needed, planes [lo-1, hi+1): the same tiling
-   // lets the acceleration pass reuse the density pass's neighbour lists.  The acceleration
-   // is only computed for the owned planes [lo, hi), a sub-range.
    const int begin = meta[META_SUM_BEGIN];
    const int end = meta[META_SUM_END];
    const int tid = threadIdx.x;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
    if (p0 >= end) return;
    const int p = p0 + tid;
-   bool live = p < end;
-   if (PASS == 1) {
-      const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
-      if (p0 + TILE_THREADS <= ob || p0 >= oe) return;  // a workgroup of ghosts only
-      live = live && p >= ob && p < oe;
-   }
+   const bool live = p < end;
+   if (tid == 0) list_overflow = 0;
    tile_load(posm, desc, L);
    if (L.desc.total > TILE_CAP) return;  // tile does not fit: the untiled kernel redoes this workgroup
-   uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
 
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
    RowRanges r;
@@ -354,34 +229,11 @@ k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
       row_ranges(g, cell_start, cx, cy, cz, r);
 #endif
    }
-   const uint32_t self_entry = (4u << QUEUE_TBITS) | (uint32_t)(p + L.desc.D[4]);
+   const int self_t = p + L.desc.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
+   uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
 
-   TiledSum<UNIT_SCALE, UNIFORM_MASS, PASS> sum;
-   if constexpr (PASS == 0) {
-      sum.nlist = my_list;
-      if (tid == 0) list_overflow = 0;
-      __syncthreads();
-   }
-   if constexpr (PASS == 1) {
-      accel_begin(k, sum.s, pi, live ? velp[p] : pi, live ? rho_in[p] : 0.0f);
-      if (!nlist_overflow[blockIdx.x]) {
-         // LIST path: the density pass left every lane's accepted neighbours (self excluded),
-         // in canonical order, in this workgroup's list block
-         const int cnt = live ? ncount[p] : 0;
-         for (int j = 0; __any(j < cnt); ++j) {
-            if (j < cnt) {
-               Staged g;
-               sum.stage_entry(g, my_list[j * TILE_THREADS], L, pi, posm, velp, aux_in);
-               sum.pair(k, g, pi, 0xffffffffu);
-            }
-         }
-         if (live) acc[p] = accel_end<UNIT_SCALE>(k, sum.s);
-         return;
-      }
-   }
-
-   int qn = 0;
+   int count = 0;
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = L.desc.D[kk];
@@ -400,40 +252,161 @@ k_full_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
             if (t0 + 8 < te) mask |= test8(L, t0 + 8, px, py, pz, k.h2) << 8;
             if (t0 + 16 < te) mask |= test8(L, t0 + 16, px, py, pz, k.h2) << 16;
             if (t0 + 24 < te) mask |= test8(L, t0 + 24, px, py, pz, k.h2) << 24;
-            // keep only slots inside [ts, te)
+            // keep only slots inside [ts, te), and not the particle itself
             const int lo = ts - t0, hi = te - t0;
             if (lo > 0) mask &= ~0u << lo;
             if (hi < 32) mask &= ~(~0u << hi);
+            if (kk == 4) {
+               const int sb = self_t - t0;
+               if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
+            }
          }
-         // expand the bits, ascending, into the lane's queue; drain whenever a queue fills
+         // append the set bits, ascending, to the lane's neighbour list
          while (__any(mask != 0u)) {
-            if (mask != 0u && qn < QUEUE_DEPTH) {
+            if (mask != 0u) {
                const int bit = __builtin_ctz(mask);
                mask &= mask - 1u;
-               L.queue[qn * TILE_THREADS + tid] = (uint16_t)(kbits | (uint32_t)(t0 + bit));
-               qn++;
-            }
-            if (__any(qn == QUEUE_DEPTH)) {
-               drain_queue(sum, k, L, tid, qn, pi, self_entry, posm, velp, aux_in);
-               qn = 0;
+               if (count < NLIST_CAP) my_list[count * TILE_THREADS] = (uint16_t)(kbits | (uint32_t)(t0 + bit));
+               count++;
             }
          }
       }
    }
-   drain_queue(sum, k, L, tid, qn, pi, self_entry, posm, velp, aux_in);
+   if (count > NLIST_CAP) list_overflow = 1;
+   __syncthreads();
+   const int give_up = list_overflow;
+   if (tid == 0) nlist_overflow[blockIdx.x] = (uint32_t)give_up;
+   if (give_up) return;  // a list did not fit: the untiled kernels redo this workgroup
 
-   if constexpr (PASS == 0) {
-      if (sum.overflow) list_overflow = 1;
-      __syncthreads();
-      if (tid == 0) nlist_overflow[blockIdx.x] = (uint32_t)list_overflow;
-   }
-   if (live) {
-      if constexpr (PASS == 0) {
-         rho_out[p] = sum.density;
-         aux_out[p] = neighbor_terms(k, sum.density, pi.w);
-         ncount[p] = sum.count;
-      } else {
-         acc[p] = accel_end<UNIT_SCALE>(k, sum.s);
+   // SUM: one pass over the list, in canonical order
+   float density = 0.0f;
+   for (int j = 0; __any(j < count); ++j) {
+      if (j < count) {
+#if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
+         const uint32_t entry = my_list[j * TILE_THREADS];
+         const int t = (int)(entry & QUEUE_TMASK);
+         float mj = pi.w;
+         if (!UNIFORM_MASS) mj = posm[t - L.desc.D[entry >> QUEUE_TBITS]].w;
+         float dx, dy, dz;
+         const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+         float d = sqrtf(d2);
+         if (!UNIT_SCALE) d *= k.sim_scale;
+         density_accumulate(k, mj, d, density);
+#endif
       }
    }
+   if (live) {
+      rho_out[p] = density;
+      const float2 bc = neighbor_terms(k, density, pi.w);
+      const float4 v = velp[p];
+      velB_out[p] = make_float4(v.x, v.y, v.z, bc.x);  // what the acceleration pass gathers
+      auxc_out[p] = bc.y;                              // ... and what it stages in its tile
+      ncount[p] = count;
+   }
+}
+
+// ---- acceleration pass: list-driven, no TEST ------------------------------------------------------
+// Same workgroups, same tile layout as the density pass (so its u16 list entries are valid
+// tile indices).  The pass is bound by the per-neighbour gathers, so the tile also holds the
+// neighbour's viscosity coefficient C_j next to x/y/z and the only global gather left per
+// neighbour is one 16-byte {vx, vy, vz, B_j}.
+struct AccelLds {
+   __attribute__((aligned(16))) float x[TILE_CAP + 32];
+   __attribute__((aligned(16))) float y[TILE_CAP + 32];
+   __attribute__((aligned(16))) float z[TILE_CAP + 32];
+   __attribute__((aligned(16))) float c[TILE_CAP + 32];
+   TileDesc desc;
+};
+
+template <bool UNIT_SCALE, bool UNIFORM_MASS>
+__global__ void __launch_bounds__(TILE_THREADS, 3)
+k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
+                   const float* __restrict__ rho, const float* __restrict__ auxc,
+                   const int32_t* __restrict__ ncount, const int32_t* __restrict__ meta,
+                   PairConsts k, float4* __restrict__ acc, const TileDesc* __restrict__ desc,
+                   const uint16_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow)
+{
+   __shared__ __attribute__((aligned(16))) AccelLds L;
+
+   const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
+   const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+   const int tid = threadIdx.x;
+   const int p0 = begin + blockIdx.x * TILE_THREADS;
+   // nothing to do for workgroups past the range or made of ghosts only; workgroups whose tile
+   // or lists overflowed are redone by the untiled kernel
+   if (p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) return;
+   if (nlist_overflow[blockIdx.x]) return;
+   if (tid < (int)(sizeof(TileDesc) / sizeof(int)))
+      reinterpret_cast<int*>(&L.desc)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
+   __syncthreads();
+   const int total = L.desc.total;
+   if (total > TILE_CAP) return;
+   {
+      int B[9], D[9];
+#pragma unroll
+      for (int kk = 0; kk < 9; kk++) {
+         B[kk] = L.desc.B[kk];
+         D[kk] = L.desc.D[kk];
+      }
+      float4 buf[TILE_ROUNDS];
+      float cbuf[TILE_ROUNDS];
+#pragma unroll
+      for (int r = 0; r < TILE_ROUNDS; r++) {
+         const int idx = tid + r * TILE_THREADS;
+         if (idx < total) {
+            int d = D[0];
+#pragma unroll
+            for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
+            buf[r] = posm[idx - d];
+            cbuf[r] = auxc[idx - d];
+         }
+      }
+#pragma unroll
+      for (int r = 0; r < TILE_ROUNDS; r++) {
+         const int idx = tid + r * TILE_THREADS;
+         if (idx < total) {
+            L.x[idx] = buf[r].x;
+            L.y[idx] = buf[r].y;
+            L.z[idx] = buf[r].z;
+            L.c[idx] = cbuf[r];
+         }
+      }
+   }
+   __syncthreads();
+
+   const int p = p0 + tid;
+   const bool live = p < end && p >= ob && p < oe;
+   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+   float4 vi = pi;
+   float rho_i = 0.0f;
+   int cnt = 0;
+   if (live) {
+      pi = posm[p];
+      vi = velB[p];
+      rho_i = rho[p];
+      cnt = ncount[p];
+   }
+   AccelState s;
+   accel_begin(k, s, pi, vi, rho_i);
+   const uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
+   for (int j = 0; __any(j < cnt); ++j) {
+      if (j < cnt) {
+         const uint32_t entry = my_list[j * TILE_THREADS];
+         const int t = (int)(entry & QUEUE_TMASK);
+         const int q = t - L.desc.D[entry >> QUEUE_TBITS];
+#if defined(SPH_ABLATE) && SPH_ABLATE == 7
+         const float4 vj = make_float4(L.x[t], L.y[t], L.z[t], L.c[t]);  // timing only: no gather
+#else
+         const float4 vj = velB[q];
+#endif
+         float mj = pi.w;
+         if (!UNIFORM_MASS) mj = posm[q].w;
+         float dx, dy, dz;
+         const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+         float d = sqrtf(d2);
+         if (!UNIT_SCALE) d *= k.sim_scale;
+         accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, vj.w, L.c[t]);
+      }
+   }
+   if (live) acc[p] = accel_end<UNIT_SCALE>(k, s);
 }

@@ -94,7 +94,8 @@ struct sph_hip_context {
 
    // sums
    float* rho = nullptr;
-   float2* aux = nullptr; // per particle {p_j * rhojInv^2, (rhojInv * m_j) * k3}
+   float4* velB = nullptr; // per particle {vx, vy, vz, B = p_j * rhojInv^2}: the acceleration gather
+   float* auxc = nullptr;  // per particle C = (rhojInv * m_j) * k3: staged in the acceleration tile
    float4* acc = nullptr; // {ax, ay, az, unused}
    int32_t* ncount = nullptr;
    struct TileDesc* tile_desc = nullptr; // per 256-particle workgroup: LDS tile layout

@@ -65,7 +65,7 @@ void free_all(sph_hip_context* ctx)
       if (ctx->velp[b]) (void)hipFree(ctx->velp[b]);
    }
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
-                   ctx->scan_part, ctx->rho, ctx->aux, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
+                   ctx->scan_part, ctx->rho, ctx->velB, ctx->auxc, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
                    ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta, ctx->nlist,
                    ctx->nlist_overflow};
    for (void* q : ptrs)
@@ -152,19 +152,33 @@ int launch_find_neighbors(sph_hip_context* ctx)
    return SPH_HIP_OK;
 }
 
-template <int PASS>
-void launch_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
+// tiled kernels of the two sums, specialised on (unit simulation scale, uniform mass)
+void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
 {
-#define SPH_TILED(U, M)                                                                          \
-   hipLaunchKernelGGL((k_full_tiled<U, M, PASS>), dim3(blocks), dim3(TILE_THREADS), 0,           \
-                      ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux, \
-                      ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->aux, ctx->ncount, \
-                      ctx->acc, ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
-   if (unit && ctx->uniform_mass) SPH_TILED(true, true);
-   else if (unit) SPH_TILED(true, false);
-   else if (ctx->uniform_mass) SPH_TILED(false, true);
-   else SPH_TILED(false, false);
-#undef SPH_TILED
+#define SPH_GO(U, M)                                                                             \
+   hipLaunchKernelGGL((k_full_density_tiled<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,         \
+                      ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
+                      ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
+                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
+   if (unit && ctx->uniform_mass) SPH_GO(true, true);
+   else if (unit) SPH_GO(true, false);
+   else if (ctx->uniform_mass) SPH_GO(false, true);
+   else SPH_GO(false, false);
+#undef SPH_GO
+}
+
+void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
+{
+#define SPH_GO(U, M)                                                                             \
+   hipLaunchKernelGGL((k_full_accel_lists<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,           \
+                      ctx->stream, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
+                      ctx->ncount, ctx->meta, k, ctx->acc, ctx->tile_desc, ctx->nlist,           \
+                      ctx->nlist_overflow)
+   if (unit && ctx->uniform_mass) SPH_GO(true, true);
+   else if (unit) SPH_GO(true, false);
+   else if (ctx->uniform_mass) SPH_GO(false, true);
+   else SPH_GO(false, false);
+#undef SPH_GO
 }
 
 int launch_density(sph_hip_context* ctx)
@@ -178,27 +192,26 @@ int launch_density(sph_hip_context* ctx)
                          ctx->nb, ctx->nd, ctx->ncount, n, ctx->prm.examine_count, k, ctx->rho);
    } else {
       const bool unit = unit_scale(ctx->prm);
-      const int* flags = nullptr;
+      const int* tile_total = nullptr;
       if (ctx->use_tiled) {
          static_assert(sizeof(TileDesc) == 20 * sizeof(int), "fallback kernels index TileDesc::total");
-         flags = &ctx->tile_desc->total;
+         tile_total = &ctx->tile_desc->total;
          hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
                             ctx->grid, blocks, ctx->tile_desc);
-         launch_tiled<0>(ctx, unit, blocks, k);
+         launch_density_tiled(ctx, unit, blocks, k);
       }
-#if defined(SPH_ABLATE) && SPH_ABLATE == 6
-      if (false) {}
-      else
-#endif
+      // untiled: everything (SPH_HIP_UNTILED=1) or only the workgroups whose tile overflowed
       if (unit)
          hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, ctx->grid, k,
-                            ctx->rho, ctx->aux, ctx->ncount, flags, TILE_CAP);
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
+                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, tile_total,
+                            TILE_CAP, ctx->nlist_overflow);
       else
          hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, ctx->grid, k,
-                            ctx->rho, ctx->aux, ctx->ncount, flags, TILE_CAP);
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
+                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, tile_total,
+                            TILE_CAP, ctx->nlist_overflow);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -216,24 +229,23 @@ int launch_accel(sph_hip_context* ctx)
                          ctx->prm.examine_count, k, ctx->acc);
    } else {
       const bool unit = unit_scale(ctx->prm);
-      const int* flags = nullptr;
+      const int* tile_total = nullptr;
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         flags = &ctx->tile_desc->total;
-         launch_tiled<1>(ctx, unit, blocks, k);
+         tile_total = &ctx->tile_desc->total;
+         launch_accel_lists(ctx, unit, blocks, k);
       }
-#if defined(SPH_ABLATE) && SPH_ABLATE == 6
-      if (false) {}
-      else
-#endif
+      // untiled: everything, or only workgroups whose tile / neighbour lists overflowed
       if (unit)
          hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
-                            ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc, flags, TILE_CAP);
+                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
+                            ctx->meta, ctx->grid, k, ctx->acc, tile_total, TILE_CAP,
+                            ctx->nlist_overflow);
       else
          hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->rho, ctx->aux,
-                            ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc, flags, TILE_CAP);
+                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
+                            ctx->meta, ctx->grid, k, ctx->acc, tile_total, TILE_CAP,
+                            ctx->nlist_overflow);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -429,7 +441,8 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    CREATE_TRY(dev_alloc(&ctx->meta, META_COUNT));
    CREATE_TRY(hipMemsetAsync(ctx->meta, 0, META_COUNT * sizeof(int32_t), ctx->stream));
    if (mode == SPH_HIP_MODE_FULL) {
-      CREATE_TRY(dev_alloc(&ctx->aux, cap));
+      CREATE_TRY(dev_alloc(&ctx->velB, cap));
+      CREATE_TRY(dev_alloc(&ctx->auxc, cap));
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
       CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_CAP * TILE_THREADS));
       CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
