@@ -31,6 +31,7 @@
 // NLIST_CAP rows of 256 u16 queue entries (row j = every lane's j-th accepted neighbour, so a
 // wave reads/writes 128 contiguous bytes).  Only rows in use are ever touched.
 #define NLIST_CAP 96
+#define LIST_UNROLL 4   // list entries fetched per trip of the SUM loops
 // queue entry: segment id << 12 | tile index (TILE_CAP + 32 <= 4096)
 #define QUEUE_TBITS 12
 #define QUEUE_TMASK 0xfffu
@@ -280,20 +281,29 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 
    // SUM: one pass over the list, in canonical order
    float density = 0.0f;
-   for (int j = 0; __any(j < count); ++j) {
-      if (j < count) {
+   for (int j0 = 0; __any(j0 < count); j0 += LIST_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
-         const uint32_t entry = my_list[j * TILE_THREADS];
-         const int t = (int)(entry & QUEUE_TMASK);
-         float mj = pi.w;
-         if (!UNIFORM_MASS) mj = posm[t - L.desc.D[entry >> QUEUE_TBITS]].w;
-         float dx, dy, dz;
-         const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-         float d = sqrtf(d2);
-         if (!UNIT_SCALE) d *= k.sim_scale;
-         density_accumulate(k, mj, d, density);
-#endif
+      uint32_t entry[LIST_UNROLL];
+      const int last = count > 0 ? count - 1 : 0;
+#pragma unroll
+      for (int u = 0; u < LIST_UNROLL; u++) {
+         const int j = j0 + u < last ? j0 + u : last;
+         entry[u] = my_list[j * TILE_THREADS];  // independent loads, all in flight together
       }
+#pragma unroll
+      for (int u = 0; u < LIST_UNROLL; u++) {
+         if (j0 + u < count) {
+            const int t = (int)(entry[u] & QUEUE_TMASK);
+            float mj = pi.w;
+            if (!UNIFORM_MASS) mj = posm[t - L.desc.D[entry[u] >> QUEUE_TBITS]].w;
+            float dx, dy, dz;
+            const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+            float d = sqrtf(d2);
+            if (!UNIT_SCALE) d *= k.sim_scale;
+            density_accumulate(k, mj, d, density);
+         }
+      }
+#endif
    }
    if (live) {
       rho_out[p] = density;
@@ -316,7 +326,10 @@ struct AccelLds {
    __attribute__((aligned(16))) float z[TILE_CAP + 32];
    __attribute__((aligned(16))) float c[TILE_CAP + 32];
    TileDesc desc;
+   int hist[2 * SPH_WAVE];         // neighbour-count histogram / its exclusive scan (NLIST_CAP+1 used)
+   uint16_t perm[TILE_THREADS];    // lane -> list column, ascending neighbour count
 };
+static_assert(NLIST_CAP + 1 <= 2 * SPH_WAVE, "count histogram is scanned by one wave, two entries per lane");
 
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
 __global__ void __launch_bounds__(TILE_THREADS, 3)
@@ -374,7 +387,38 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    }
    __syncthreads();
 
-   const int p = p0 + tid;
+   // Lane <-> particle assignment: the loop below runs to the largest neighbour count in the
+   // wave, so lanes are handed particles in order of their count (counting sort through LDS):
+   // every wave then works on particles with nearly equal counts.  Each lane's sum is
+   // independent, so the assignment does not change any result.
+   int my_cnt = 0;
+   {
+      const int pp = p0 + tid;
+      if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
+   }
+   if (tid <= NLIST_CAP) L.hist[tid] = 0;
+   __syncthreads();
+   const int slot = atomicAdd(&L.hist[my_cnt], 1);
+   __syncthreads();
+   if (tid < SPH_WAVE) {
+      // exclusive scan of hist[0..NLIST_CAP] by one wave (two entries per lane)
+      const int a = L.hist[2 * tid], b = (2 * tid + 1 <= NLIST_CAP) ? L.hist[2 * tid + 1] : 0;
+      int inc = a + b;
+#pragma unroll
+      for (int dd = 1; dd < SPH_WAVE; dd <<= 1) {
+         const int o = __shfl_up(inc, dd);
+         if (tid >= dd) inc += o;
+      }
+      const int ex = inc - (a + b);
+      L.hist[2 * tid] = ex;
+      if (2 * tid + 1 <= NLIST_CAP) L.hist[2 * tid + 1] = ex + a;
+   }
+   __syncthreads();
+   L.perm[L.hist[my_cnt] + slot] = (uint16_t)tid;
+   __syncthreads();
+   const int col = L.perm[tid];  // the particle (column of the list block) this lane works on
+
+   const int p = p0 + col;
    const bool live = p < end && p >= ob && p < oe;
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
    float4 vi = pi;
@@ -388,24 +432,44 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    }
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
-   const uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
-   for (int j = 0; __any(j < cnt); ++j) {
-      if (j < cnt) {
-         const uint32_t entry = my_list[j * TILE_THREADS];
-         const int t = (int)(entry & QUEUE_TMASK);
-         const int q = t - L.desc.D[entry >> QUEUE_TBITS];
+   const uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + col;
+   // Four neighbours per trip: their list entries (global) and their {v,B} gathers are issued
+   // back to back before the first pair's arithmetic, so the two dependent memory round trips
+   // of a neighbour overlap with its predecessors' math.  Lanes past their count re-read their
+   // last entry (valid address, result unused).
+   for (int j0 = 0; __any(j0 < cnt); j0 += LIST_UNROLL) {
+      uint32_t entry[LIST_UNROLL];
+      float4 vj[LIST_UNROLL];
+      float mj[LIST_UNROLL];
+      const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+      for (int u = 0; u < LIST_UNROLL; u++) {
+         const int j = j0 + u < last ? j0 + u : last;
+         entry[u] = my_list[j * TILE_THREADS];
+      }
+#pragma unroll
+      for (int u = 0; u < LIST_UNROLL; u++) {
+         const int q = (int)(entry[u] & QUEUE_TMASK) - L.desc.D[entry[u] >> QUEUE_TBITS];
+         const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
 #if defined(SPH_ABLATE) && SPH_ABLATE == 7
-         const float4 vj = make_float4(L.x[t], L.y[t], L.z[t], L.c[t]);  // timing only: no gather
+         vj[u] = make_float4(1.f, 2.f, 3.f, 4.f);  // timing only: no gather
 #else
-         const float4 vj = velB[q];
+         vj[u] = velB[qq];
 #endif
-         float mj = pi.w;
-         if (!UNIFORM_MASS) mj = posm[q].w;
-         float dx, dy, dz;
-         const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-         float d = sqrtf(d2);
-         if (!UNIT_SCALE) d *= k.sim_scale;
-         accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, vj.w, L.c[t]);
+         mj[u] = pi.w;
+         if (!UNIFORM_MASS) mj[u] = posm[qq].w;
+      }
+#pragma unroll
+      for (int u = 0; u < LIST_UNROLL; u++) {
+         if (j0 + u < cnt) {
+            const int t = (int)(entry[u] & QUEUE_TMASK);
+            float dx, dy, dz;
+            const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+            float d = sqrtf(d2);
+            if (!UNIT_SCALE) d *= k.sim_scale;
+            accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
+                                   L.c[t]);
+         }
       }
    }
    if (live) acc[p] = accel_end<UNIT_SCALE>(k, s);
