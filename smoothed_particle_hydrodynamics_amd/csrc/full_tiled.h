@@ -31,7 +31,9 @@
 // NLIST_CAP rows of 256 u16 queue entries (row j = every lane's j-th accepted neighbour, so a
 // wave reads/writes 128 contiguous bytes).  Only rows in use are ever touched.
 #define NLIST_CAP 96
-#define LIST_UNROLL 4   // list entries fetched per trip of the SUM loops
+// list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
+#define DENSITY_UNROLL 6
+#define ACCEL_UNROLL 8
 // queue entry: segment id << 12 | tile index (TILE_CAP + 32 <= 4096)
 #define QUEUE_TBITS 12
 #define QUEUE_TMASK 0xfffu
@@ -281,17 +283,17 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 
    // SUM: one pass over the list, in canonical order
    float density = 0.0f;
-   for (int j0 = 0; __any(j0 < count); j0 += LIST_UNROLL) {
+   for (int j0 = 0; __any(j0 < count); j0 += DENSITY_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
-      uint32_t entry[LIST_UNROLL];
+      uint32_t entry[DENSITY_UNROLL];
       const int last = count > 0 ? count - 1 : 0;
 #pragma unroll
-      for (int u = 0; u < LIST_UNROLL; u++) {
+      for (int u = 0; u < DENSITY_UNROLL; u++) {
          const int j = j0 + u < last ? j0 + u : last;
          entry[u] = my_list[j * TILE_THREADS];  // independent loads, all in flight together
       }
 #pragma unroll
-      for (int u = 0; u < LIST_UNROLL; u++) {
+      for (int u = 0; u < DENSITY_UNROLL; u++) {
          if (j0 + u < count) {
             const int t = (int)(entry[u] & QUEUE_TMASK);
             float mj = pi.w;
@@ -437,18 +439,18 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // back to back before the first pair's arithmetic, so the two dependent memory round trips
    // of a neighbour overlap with its predecessors' math.  Lanes past their count re-read their
    // last entry (valid address, result unused).
-   for (int j0 = 0; __any(j0 < cnt); j0 += LIST_UNROLL) {
-      uint32_t entry[LIST_UNROLL];
-      float4 vj[LIST_UNROLL];
-      float mj[LIST_UNROLL];
+   for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
+      uint32_t entry[ACCEL_UNROLL];
+      float4 vj[ACCEL_UNROLL];
+      float mj[ACCEL_UNROLL];
       const int last = cnt > 0 ? cnt - 1 : 0;
 #pragma unroll
-      for (int u = 0; u < LIST_UNROLL; u++) {
+      for (int u = 0; u < ACCEL_UNROLL; u++) {
          const int j = j0 + u < last ? j0 + u : last;
          entry[u] = my_list[j * TILE_THREADS];
       }
 #pragma unroll
-      for (int u = 0; u < LIST_UNROLL; u++) {
+      for (int u = 0; u < ACCEL_UNROLL; u++) {
          const int q = (int)(entry[u] & QUEUE_TMASK) - L.desc.D[entry[u] >> QUEUE_TBITS];
          const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
 #if defined(SPH_ABLATE) && SPH_ABLATE == 7
@@ -460,7 +462,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          if (!UNIFORM_MASS) mj[u] = posm[qq].w;
       }
 #pragma unroll
-      for (int u = 0; u < LIST_UNROLL; u++) {
+      for (int u = 0; u < ACCEL_UNROLL; u++) {
          if (j0 + u < cnt) {
             const int t = (int)(entry[u] & QUEUE_TMASK);
             float dx, dy, dz;
