@@ -224,9 +224,15 @@ k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ ke
    const float4 v = velp_in[i];
    const uint32_t id = __float_as_uint(v.w);
    uint32_t rank = 0;
-   for (uint32_t q = s; q < e; q++) {
-      const uint32_t other = __float_as_uint(velp_in[perm[q]].w);
-      rank += (other < id) ? 1u : 0u;
+   // four cell members per trip: their two dependent loads (perm, then id) overlap
+   for (uint32_t q0 = s; q0 < e; q0 += 4) {
+      uint32_t other[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) other[u] = perm[q0 + u < e ? q0 + u : e - 1];
+#pragma unroll
+      for (int u = 0; u < 4; u++) other[u] = __float_as_uint(velp_in[other[u]].w);
+#pragma unroll
+      for (int u = 0; u < 4; u++) rank += (q0 + u < e && other[u] < id) ? 1u : 0u;
    }
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;

@@ -109,16 +109,22 @@ k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_s
    desc[tile] = d;
 }
 
+template <class Lds>
+__device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, Lds& L)
+{
+   const int tid = threadIdx.x;
+   if (tid < (int)(sizeof(TileDesc) / sizeof(int)))
+      reinterpret_cast<int*>(&L.desc)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
+   __syncthreads();
+}
+
 // Copies the candidate positions of the workgroup's tile into LDS: every thread issues all of
 // its (at most TILE_ROUNDS) 16-byte loads before the first LDS store.
 __device__ __forceinline__ void tile_load(const float4* __restrict__ posm,
                                           const TileDesc* __restrict__ desc, TileLds& L)
 {
    const int tid = threadIdx.x;
-   if (tid < (int)(sizeof(TileDesc) / sizeof(int)))
-      reinterpret_cast<int*>(&L.desc)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
-   __syncthreads();
-   const int total = L.desc.total;
+   const int total = L.desc.total;  // descriptor already in LDS (tile_desc_load)
 #if defined(SPH_ABLATE) && (SPH_ABLATE == 3 || SPH_ABLATE == 5)
    if (false) {
 #else
@@ -217,21 +223,24 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const int p = p0 + tid;
    const bool live = p < end;
    if (tid == 0) list_overflow = 0;
-   tile_load(posm, desc, L);
-   if (L.desc.total > TILE_CAP) return;  // tile does not fit: the untiled kernel redoes this workgroup
-
+   // Prologue ordered to shorten the dependent-latency chain: the particle's own position is
+   // requested first, then the tile descriptor; the 18 cell_start lookups of the lane's ranges go
+   // out before the tile's loads, so that both are in flight together.
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+   if (live) pi = posm[p];
+   tile_desc_load(desc, L);
+   if (L.desc.total > TILE_CAP) return;  // tile does not fit: the untiled kernel redoes this workgroup
    RowRanges r;
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) r.s[kk] = r.e[kk] = 0;
    if (live) {
-      pi = posm[p];
 #if !(defined(SPH_ABLATE) && (SPH_ABLATE == 4 || SPH_ABLATE == 5))
       int cx, cy, cz;
       cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
       row_ranges(g, cell_start, cx, cy, cz, r);
 #endif
    }
+   tile_load(posm, desc, L);
    const int self_t = p + L.desc.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
    uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
@@ -351,9 +360,12 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // or lists overflowed are redone by the untiled kernel
    if (p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) return;
    if (nlist_overflow[blockIdx.x]) return;
-   if (tid < (int)(sizeof(TileDesc) / sizeof(int)))
-      reinterpret_cast<int*>(&L.desc)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
-   __syncthreads();
+   int my_cnt = 0;  // requested before the tile: the lane permutation below needs it
+   {
+      const int pp = p0 + tid;
+      if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
+   }
+   tile_desc_load(desc, L);
    const int total = L.desc.total;
    if (total > TILE_CAP) return;
    {
@@ -393,11 +405,6 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // wave, so lanes are handed particles in order of their count (counting sort through LDS):
    // every wave then works on particles with nearly equal counts.  Each lane's sum is
    // independent, so the assignment does not change any result.
-   int my_cnt = 0;
-   {
-      const int pp = p0 + tid;
-      if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
-   }
    if (tid <= NLIST_CAP) L.hist[tid] = 0;
    __syncthreads();
    const int slot = atomicAdd(&L.hist[my_cnt], 1);

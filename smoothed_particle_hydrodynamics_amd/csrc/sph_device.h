@@ -112,6 +112,7 @@ struct sph_hip_context {
    // reductions
    double* epart = nullptr; // 2 * blocks partial sums, then [0],[1] totals
    int eblocks = 0;
+   int energy_blocks = 0;   // partials written by the last integrate (0 = none yet)
    int32_t* stats = nullptr; // sum(lo,hi), max, min
 
    // staging for host <-> device in the reference's interleaved layouts

@@ -265,8 +265,7 @@ int launch_integrate(sph_hip_context* ctx)
       hipLaunchKernelGGL(k_integrate<false>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
                          ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k,
                          ctx->epart + 2);
-   hipLaunchKernelGGL(k_energy_total, dim3(1), dim3(RED_THREADS), 0, ctx->stream, ctx->epart + 2,
-                      blocks, ctx->epart);
+   ctx->energy_blocks = blocks;  // totals are formed on demand (sph_hip_get_energy)
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
 }
@@ -815,6 +814,12 @@ int sph_hip_get_energy(sph_hip_context* ctx, float* kinetic, float* potential)
    int rc = check_ctx(ctx);
    if (rc) return rc;
    double e[2] = {0.0, 0.0};
+   if (ctx->energy_blocks > 0) {
+      // per-workgroup partial sums of the last integrate -> totals, fixed order
+      hipLaunchKernelGGL(k_energy_total, dim3(1), dim3(RED_THREADS), 0, ctx->stream,
+                         ctx->epart + 2, ctx->energy_blocks, ctx->epart);
+      SPH_TRY(hipGetLastError());
+   }
    SPH_TRY(hipMemcpyAsync(e, ctx->epart, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
    SPH_TRY(hipStreamSynchronize(ctx->stream));
    if (kinetic) *kinetic = (float)e[0];
