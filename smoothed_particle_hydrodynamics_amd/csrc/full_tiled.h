@@ -332,10 +332,9 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // neighbour's viscosity coefficient C_j next to x/y/z and the only global gather left per
 // neighbour is one 16-byte {vx, vy, vz, B_j}.
 struct AccelLds {
-   __attribute__((aligned(16))) float x[TILE_CAP + 32];
-   __attribute__((aligned(16))) float y[TILE_CAP + 32];
-   __attribute__((aligned(16))) float z[TILE_CAP + 32];
-   __attribute__((aligned(16))) float c[TILE_CAP + 32];
+   // array of {x, y, z, C}: this pass never scans the tile, it only looks single neighbours up,
+   // so one ds_read_b128 per neighbour beats four scattered ds_read_b32
+   float4 xyzc[TILE_CAP + 32];
    TileDesc desc;
    int hist[2 * SPH_WAVE];         // neighbour-count histogram / its exclusive scan (NLIST_CAP+1 used)
    uint16_t perm[TILE_THREADS];    // lane -> list column, ascending neighbour count
@@ -391,12 +390,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
       for (int r = 0; r < TILE_ROUNDS; r++) {
          const int idx = tid + r * TILE_THREADS;
-         if (idx < total) {
-            L.x[idx] = buf[r].x;
-            L.y[idx] = buf[r].y;
-            L.z[idx] = buf[r].z;
-            L.c[idx] = cbuf[r];
-         }
+         if (idx < total) L.xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
       }
    }
    __syncthreads();
@@ -442,22 +436,20 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
    const uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + col;
-   // Four neighbours per trip: their list entries (global) and their {v,B} gathers are issued
-   // back to back before the first pair's arithmetic, so the two dependent memory round trips
-   // of a neighbour overlap with its predecessors' math.  Lanes past their count re-read their
-   // last entry (valid address, result unused).
+   // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
+   // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
+   // so neither of a neighbour's two dependent memory round trips is waited for in isolation.
+   // Lanes past their count re-read their last entry (valid address, result unused).
+   const int last = cnt > 0 ? cnt - 1 : 0;
+   uint32_t entry[ACCEL_UNROLL], next_entry[ACCEL_UNROLL];
+#pragma unroll
+   for (int u = 0; u < ACCEL_UNROLL; u++) next_entry[u] = my_list[(u < last ? u : last) * TILE_THREADS];
    for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
-      uint32_t entry[ACCEL_UNROLL];
       float4 vj[ACCEL_UNROLL];
       float mj[ACCEL_UNROLL];
-      const int last = cnt > 0 ? cnt - 1 : 0;
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
-         const int j = j0 + u < last ? j0 + u : last;
-         entry[u] = my_list[j * TILE_THREADS];
-      }
-#pragma unroll
-      for (int u = 0; u < ACCEL_UNROLL; u++) {
+         entry[u] = next_entry[u];
          const int q = (int)(entry[u] & QUEUE_TMASK) - L.desc.D[entry[u] >> QUEUE_TBITS];
          const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
 #if defined(SPH_ABLATE) && SPH_ABLATE == 7
@@ -468,16 +460,22 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          mj[u] = pi.w;
          if (!UNIFORM_MASS) mj[u] = posm[qq].w;
       }
+      // the next trip's list entries travel while this trip's pairs are computed
+#pragma unroll
+      for (int u = 0; u < ACCEL_UNROLL; u++) {
+         const int j = j0 + ACCEL_UNROLL + u;
+         next_entry[u] = my_list[(j < last ? j : last) * TILE_THREADS];
+      }
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          if (j0 + u < cnt) {
-            const int t = (int)(entry[u] & QUEUE_TMASK);
+            const float4 pj = L.xyzc[entry[u] & QUEUE_TMASK];
             float dx, dy, dz;
-            const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+            const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             float d = sqrtf(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
             accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
-                                   L.c[t]);
+                                   pj.w);
          }
       }
    }
