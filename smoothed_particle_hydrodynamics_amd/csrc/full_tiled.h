@@ -28,9 +28,12 @@
 #define TILE_THREADS 256
 #define TILE_CAP 3008   // candidate positions per workgroup tile (3 x 11.9 KiB; 3 workgroups per CU)
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
-// NLIST_CAP rows of 256 u16 queue entries (row j = every lane's j-th accepted neighbour, so a
-// wave reads/writes 128 contiguous bytes).  Only rows in use are ever touched.
+// NLIST_WORDS rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
+// reads/writes 256 contiguous bytes).  Only rows in use are ever touched.
 #define NLIST_CAP 96
+// two entries per 32-bit word: word r of a lane holds its entries 2r (low half) and 2r+1;
+// one spare word row swallows overflowing appends
+#define NLIST_WORDS (NLIST_CAP / 2 + 1)
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
 #define DENSITY_UNROLL 6
 #define ACCEL_UNROLL 8
@@ -47,6 +50,7 @@ __device__ __forceinline__ f32x4 lds_read4(const float* base, int i)
    return *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + i, 16));
 }
 
+static_assert(DENSITY_UNROLL % 2 == 0 && ACCEL_UNROLL % 2 == 0 && NLIST_CAP % 2 == 0, "entries travel in pairs");
 static_assert(TILE_CAP + 32 <= (1 << QUEUE_TBITS), "tile index must fit the queue entry");
 #define TILE_ROUNDS ((TILE_CAP + TILE_THREADS - 1) / TILE_THREADS)
 
@@ -210,7 +214,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                      CellGrid g, PairConsts k, float* __restrict__ rho_out,
                      float4* __restrict__ velB_out, float* __restrict__ auxc_out,
                      int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
-                     uint16_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow)
+                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow)
 {
    __shared__ __attribute__((aligned(16))) TileLds L;
    __shared__ int list_overflow;
@@ -243,9 +247,12 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    tile_load(posm, desc, L);
    const int self_t = p + L.desc.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
-   uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + tid;
+   // uniform base of the workgroup's list block; lanes address it with 32-bit offsets
+   uint32_t* list_block = nlist + (size_t)blockIdx.x * (NLIST_WORDS * TILE_THREADS);
+   const uint32_t* my_list = list_block + tid;
 
    int count = 0;
+   uint32_t hold = 0;  // an even-numbered entry waiting for its partner
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = L.desc.D[kk];
@@ -273,17 +280,27 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
             }
          }
-         // append the set bits, ascending, to the lane's neighbour list
+         // append the set bits, ascending, to the lane's neighbour list: an even entry waits in
+         // a register, an odd one completes a 32-bit word and stores it (half the scattered
+         // stores); words past NLIST_CAP all land in the spare row (workgroup flagged, redone)
          while (__any(mask != 0u)) {
             if (mask != 0u) {
-               const int bit = __builtin_ctz(mask);
+               const uint32_t bit = (uint32_t)__builtin_ctz(mask);
                mask &= mask - 1u;
-               if (count < NLIST_CAP) my_list[count * TILE_THREADS] = (uint16_t)(kbits | (uint32_t)(t0 + bit));
+               const uint32_t entry = kbits | ((uint32_t)t0 + bit);
+               if (count & 1) {
+                  const uint32_t row = count < NLIST_CAP ? (uint32_t)count >> 1 : (uint32_t)(NLIST_CAP / 2);
+                  list_block[row * TILE_THREADS + (uint32_t)tid] = hold | (entry << 16);
+               } else {
+                  hold = entry;
+               }
                count++;
             }
          }
       }
    }
+   if ((count & 1) && count < NLIST_CAP)
+      list_block[((uint32_t)count >> 1) * TILE_THREADS + (uint32_t)tid] = hold;
    if (count > NLIST_CAP) list_overflow = 1;
    __syncthreads();
    const int give_up = list_overflow;
@@ -295,11 +312,13 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    for (int j0 = 0; __any(j0 < count); j0 += DENSITY_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
       uint32_t entry[DENSITY_UNROLL];
-      const int last = count > 0 ? count - 1 : 0;
+      const int lastw = count > 0 ? (count - 1) >> 1 : 0;
 #pragma unroll
-      for (int u = 0; u < DENSITY_UNROLL; u++) {
-         const int j = j0 + u < last ? j0 + u : last;
-         entry[u] = my_list[j * TILE_THREADS];  // independent loads, all in flight together
+      for (int u = 0; u < DENSITY_UNROLL; u += 2) {
+         const int w = ((j0 + u) >> 1) < lastw ? ((j0 + u) >> 1) : lastw;
+         const uint32_t word = my_list[w * TILE_THREADS];  // independent loads, all in flight
+         entry[u] = word & 0xffffu;
+         entry[u + 1] = word >> 16;
       }
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u++) {
@@ -347,7 +366,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                    const float* __restrict__ rho, const float* __restrict__ auxc,
                    const int32_t* __restrict__ ncount, const int32_t* __restrict__ meta,
                    PairConsts k, float4* __restrict__ acc, const TileDesc* __restrict__ desc,
-                   const uint16_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow)
+                   const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow)
 {
    __shared__ __attribute__((aligned(16))) AccelLds L;
 
@@ -435,21 +454,21 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    }
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
-   const uint16_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_CAP * TILE_THREADS) + col;
+   const uint32_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_WORDS * TILE_THREADS) + col;
    // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
    // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
    // so neither of a neighbour's two dependent memory round trips is waited for in isolation.
    // Lanes past their count re-read their last entry (valid address, result unused).
-   const int last = cnt > 0 ? cnt - 1 : 0;
-   uint32_t entry[ACCEL_UNROLL], next_entry[ACCEL_UNROLL];
+   const int lastw = cnt > 0 ? (cnt - 1) >> 1 : 0;
+   uint32_t entry[ACCEL_UNROLL], next_word[ACCEL_UNROLL / 2];
 #pragma unroll
-   for (int u = 0; u < ACCEL_UNROLL; u++) next_entry[u] = my_list[(u < last ? u : last) * TILE_THREADS];
+   for (int u = 0; u < ACCEL_UNROLL / 2; u++) next_word[u] = my_list[(u < lastw ? u : lastw) * TILE_THREADS];
    for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
       float4 vj[ACCEL_UNROLL];
       float mj[ACCEL_UNROLL];
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
-         entry[u] = next_entry[u];
+         entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
          const int q = (int)(entry[u] & QUEUE_TMASK) - L.desc.D[entry[u] >> QUEUE_TBITS];
          const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
 #if defined(SPH_ABLATE) && SPH_ABLATE == 7
@@ -462,9 +481,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       }
       // the next trip's list entries travel while this trip's pairs are computed
 #pragma unroll
-      for (int u = 0; u < ACCEL_UNROLL; u++) {
-         const int j = j0 + ACCEL_UNROLL + u;
-         next_entry[u] = my_list[(j < last ? j : last) * TILE_THREADS];
+      for (int u = 0; u < ACCEL_UNROLL / 2; u++) {
+         const int w = (j0 + ACCEL_UNROLL) / 2 + u;
+         next_word[u] = my_list[(w < lastw ? w : lastw) * TILE_THREADS];
       }
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {

@@ -99,7 +99,7 @@ struct sph_hip_context {
    float4* acc = nullptr; // {ax, ay, az, unused}
    int32_t* ncount = nullptr;
    struct TileDesc* tile_desc = nullptr; // per 256-particle workgroup: LDS tile layout
-   uint16_t* nlist = nullptr;            // neighbour lists density pass -> acceleration pass
+   uint32_t* nlist = nullptr;            // neighbour lists density pass -> acceleration pass
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = a list did not fit (re-test)
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)

@@ -443,7 +443,7 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(dev_alloc(&ctx->velB, cap));
       CREATE_TRY(dev_alloc(&ctx->auxc, cap));
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
-      CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_CAP * TILE_THREADS));
+      CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS));
       CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
       if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
    } else {
