@@ -45,14 +45,16 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
                const float4* __restrict__ velp, const int32_t* __restrict__ meta, CellGrid g,
                PairConsts k, float* __restrict__ rho, float4* __restrict__ velB,
                float* __restrict__ auxc, int32_t* __restrict__ ncount,
-               const int* __restrict__ tile_total, int tile_cap,
-               const uint32_t* __restrict__ list_overflow)
+               const uint32_t* __restrict__ redo)
 {
-   // as the fallback of the tiled kernel: run only the workgroups whose tile or neighbour lists
-   // overflowed (tile_total points at TileDesc::total of workgroup 0, stride 20 ints)
-   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap && !list_overflow[blockIdx.x]) return;
-   const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= meta[META_SUM_END]) return;
+   // redo == nullptr: every workgroup (SPH_HIP_UNTILED=1).  Otherwise the fallback of the tiled
+   // kernel: redo[0] = number of 256-particle workgroups it gave up on (tile or neighbour list
+   // did not fit), redo[1..] = their indices; a small grid walks that list.
+   const int nwork = redo ? (int)redo[0] : (int)gridDim.x;
+   for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
+   const int wg = redo ? (int)redo[1 + w] : w;
+   const int p = meta[META_SUM_BEGIN] + wg * blockDim.x + threadIdx.x;
+   if (p >= meta[META_SUM_END]) continue;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
@@ -82,6 +84,7 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
    velB[p] = make_float4(v.x, v.y, v.z, bc.x);
    auxc[p] = bc.y;
    ncount[p] = count;
+   }
 }
 
 // ---- acceleration, untiled ------------------------------------------------------------------------
@@ -90,15 +93,16 @@ __global__ void __launch_bounds__(256)
 k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
              const float* __restrict__ rho, const float* __restrict__ auxc,
              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
-             PairConsts k, float4* __restrict__ acc, const int* __restrict__ tile_total,
-             int tile_cap, const uint32_t* __restrict__ list_overflow)
+             PairConsts k, float4* __restrict__ acc, const uint32_t* __restrict__ redo)
 {
-   // fallback of the tiled list kernel: workgroups whose tile or neighbour lists overflowed
-   if (tile_total && tile_total[20 * blockIdx.x] <= tile_cap && !list_overflow[blockIdx.x]) return;
+   // same scheme as k_full_density: all workgroups, or the tiled pass's give-up list
+   const int nwork = redo ? (int)redo[0] : (int)gridDim.x;
+   for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
+   const int wg = redo ? (int)redo[1 + w] : w;
    // same workgroup -> particle mapping as the tiled kernels (from the density range); the
    // acceleration is only needed for owned particles
-   const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
-   if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) return;
+   const int p = meta[META_SUM_BEGIN] + wg * blockDim.x + threadIdx.x;
+   if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) continue;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
@@ -123,4 +127,5 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
       }
    }
    acc[p] = accel_end<UNIT_SCALE>(k, s);
+   }
 }

@@ -74,9 +74,10 @@ struct TileLds {
 __global__ void __launch_bounds__(256)
 k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
             const int32_t* __restrict__ meta, int range, CellGrid g, int ntiles,
-            TileDesc* __restrict__ desc)
+            TileDesc* __restrict__ desc, uint32_t* __restrict__ redo)
 {
    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+   if (tile == 0) redo[0] = 0u;  // the tiled density pass appends the workgroups it gives up on
    if (tile >= ntiles) return;
    const int begin = meta[range], end = meta[range + 1];
    const int p0 = begin + tile * TILE_THREADS;
@@ -214,7 +215,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                      CellGrid g, PairConsts k, float* __restrict__ rho_out,
                      float4* __restrict__ velB_out, float* __restrict__ auxc_out,
                      int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
-                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow)
+                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
+                     uint32_t* __restrict__ redo)
 {
    __shared__ __attribute__((aligned(16))) TileLds L;
    __shared__ int list_overflow;
@@ -233,7 +235,14 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
    if (live) pi = posm[p];
    tile_desc_load(desc, L);
-   if (L.desc.total > TILE_CAP) return;  // tile does not fit: the untiled kernel redoes this workgroup
+   if (L.desc.total > TILE_CAP) {
+      // tile does not fit: hand the workgroup to the untiled kernels
+      if (tid == 0) {
+         nlist_overflow[blockIdx.x] = 1u;
+         redo[1 + atomicAdd(&redo[0], 1u)] = blockIdx.x;
+      }
+      return;
+   }
    RowRanges r;
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) r.s[kk] = r.e[kk] = 0;
@@ -304,7 +313,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    if (count > NLIST_CAP) list_overflow = 1;
    __syncthreads();
    const int give_up = list_overflow;
-   if (tid == 0) nlist_overflow[blockIdx.x] = (uint32_t)give_up;
+   if (tid == 0) {
+      nlist_overflow[blockIdx.x] = (uint32_t)give_up;
+      if (give_up) redo[1 + atomicAdd(&redo[0], 1u)] = blockIdx.x;
+   }
    if (give_up) return;  // a list did not fit: the untiled kernels redo this workgroup
 
    // SUM: one pass over the list, in canonical order
@@ -377,7 +389,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // nothing to do for workgroups past the range or made of ghosts only; workgroups whose tile
    // or lists overflowed are redone by the untiled kernel
    if (p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) return;
-   if (nlist_overflow[blockIdx.x]) return;
+   if (nlist_overflow[blockIdx.x]) return;  // tile or lists did not fit: redone untiled
    int my_cnt = 0;  // requested before the tile: the lane permutation below needs it
    {
       const int pp = p0 + tid;

@@ -20,6 +20,9 @@
 
 namespace {
 
+// grid of the untiled kernels when they only walk the tiled pass's give-up list
+constexpr int REDO_GRID = 1024;
+
 std::string g_create_error;
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
@@ -67,7 +70,7 @@ void free_all(sph_hip_context* ctx)
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
                    ctx->scan_part, ctx->rho, ctx->velB, ctx->auxc, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
                    ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta, ctx->nlist,
-                   ctx->nlist_overflow};
+                   ctx->nlist_overflow, ctx->redo};
    for (void* q : ptrs)
       if (q) (void)hipFree(q);
    if (ctx->ev) {
@@ -159,7 +162,7 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
    hipLaunchKernelGGL((k_full_density_tiled<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,         \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
                       ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
-                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
+                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, ctx->redo)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -192,26 +195,26 @@ int launch_density(sph_hip_context* ctx)
                          ctx->nb, ctx->nd, ctx->ncount, n, ctx->prm.examine_count, k, ctx->rho);
    } else {
       const bool unit = unit_scale(ctx->prm);
-      const int* tile_total = nullptr;
+      const uint32_t* redo = nullptr;
+      int ublocks = blocks;
       if (ctx->use_tiled) {
-         static_assert(sizeof(TileDesc) == 20 * sizeof(int), "fallback kernels index TileDesc::total");
-         tile_total = &ctx->tile_desc->total;
+         redo = ctx->redo;
+         ublocks = blocks < REDO_GRID ? blocks : REDO_GRID;
          hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
-                            ctx->grid, blocks, ctx->tile_desc);
+                            ctx->grid, blocks, ctx->tile_desc, ctx->redo);
          launch_density_tiled(ctx, unit, blocks, k);
       }
-      // untiled: everything (SPH_HIP_UNTILED=1) or only the workgroups whose tile overflowed
+      // untiled: everything (SPH_HIP_UNTILED=1), or a small grid walking the tiled pass's
+      // give-up list (usually empty)
       if (unit)
-         hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+         hipLaunchKernelGGL(k_full_density<true>, dim3(ublocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
-                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, tile_total,
-                            TILE_CAP, ctx->nlist_overflow);
+                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, redo);
       else
-         hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+         hipLaunchKernelGGL(k_full_density<false>, dim3(ublocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
-                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, tile_total,
-                            TILE_CAP, ctx->nlist_overflow);
+                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, redo);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -229,23 +232,22 @@ int launch_accel(sph_hip_context* ctx)
                          ctx->prm.examine_count, k, ctx->acc);
    } else {
       const bool unit = unit_scale(ctx->prm);
-      const int* tile_total = nullptr;
+      const uint32_t* redo = nullptr;
+      int ublocks = blocks;
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         tile_total = &ctx->tile_desc->total;
+         redo = ctx->redo;
+         ublocks = blocks < REDO_GRID ? blocks : REDO_GRID;
          launch_accel_lists(ctx, unit, blocks, k);
       }
-      // untiled: everything, or only workgroups whose tile / neighbour lists overflowed
       if (unit)
-         hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+         hipLaunchKernelGGL(k_full_accel<true>, dim3(ublocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                            ctx->meta, ctx->grid, k, ctx->acc, tile_total, TILE_CAP,
-                            ctx->nlist_overflow);
+                            ctx->meta, ctx->grid, k, ctx->acc, redo);
       else
-         hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+         hipLaunchKernelGGL(k_full_accel<false>, dim3(ublocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                            ctx->meta, ctx->grid, k, ctx->acc, tile_total, TILE_CAP,
-                            ctx->nlist_overflow);
+                            ctx->meta, ctx->grid, k, ctx->acc, redo);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -445,6 +447,8 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
       CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS));
       CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
+      CREATE_TRY(dev_alloc(&ctx->redo, (size_t)div_up(capacity, TILE_THREADS) + 2));
+      CREATE_TRY(hipMemsetAsync(ctx->redo, 0, sizeof(uint32_t), ctx->stream));
       if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
    } else {
       CREATE_TRY(dev_alloc(&ctx->order, cap));
