@@ -223,7 +223,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "density+acceleration pass (k_full_tiled<.,.,0> + k_full_tiled<.,.,1>)",
+                "kernel": "density+acceleration pass (k_full_density_tiled + k_full_accel_lists)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

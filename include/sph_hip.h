@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPH_HIP_ABI_VERSION 1
+#define SPH_HIP_ABI_VERSION 2
 
 typedef enum sph_hip_status {
    SPH_HIP_OK = 0,
@@ -78,6 +78,15 @@ typedef struct sph_hip_params {
    /* FULL-mode grid (no reference counterpart): cell edge >= h */
    int32_t full_cells_x, full_cells_y, full_cells_z;
    float full_cell_inv;
+   /* Dam-break physics the reference defines but never wires; both 0 =
+    * shipped behaviour.
+    *   apply_gravity: mGravity is added wherever the reference adds its point-mass gravity
+    *                  (computeAcceleration src/sph.cpp:913-915 and integrate :987-989).
+    *   apply_walls:   integrate passes (old position, new velocity, dt, new position) through
+    *                  SPH::handleBoundaryConditions / applyBoundary (src/sph.cpp:1025-1148):
+    *                  per-axis reflection at 0 / mMax*, remaining path scaled by mDamping. */
+   int32_t apply_gravity;
+   int32_t apply_walls;
 } sph_hip_params;
 
 typedef struct sph_hip_context sph_hip_context;

@@ -38,6 +38,7 @@ class OracleParams(C.Structure):
         ("examine_count", C.c_int32),
         ("full_cells_x", C.c_int32), ("full_cells_y", C.c_int32), ("full_cells_z", C.c_int32),
         ("full_cell_inv", C.c_float),
+        ("apply_gravity", C.c_int32), ("apply_walls", C.c_int32),
     ]
 
     def as_dict(self):
@@ -125,6 +126,16 @@ class Oracle:
         self.lib.oracle_accel_lists(C.byref(p), n, cap, _ptr(nb), _ptr(nd), _ptr(cnt), _ptr(pos),
                                     _ptr(vel), _ptr(mass), _ptr(rho), _ptr(acc))
         return acc
+
+    def boundary(self, p, position, vel, time_step, newpos):
+        """oracle_boundary on every particle; returns (vel, newpos) copies."""
+        position = _f32(position)
+        vel = _f32(vel).copy()
+        newpos = _f32(newpos).copy()
+        for i in range(position.size // 3):
+            self.lib.oracle_boundary(C.byref(p), _ptr(position[3 * i:]), _ptr(vel[3 * i:]),
+                                     C.c_float(time_step), _ptr(newpos[3 * i:]))
+        return vel, newpos
 
     def integrate(self, p, pos, vel, acc, mass):
         """in place on pos/vel; returns (ke, pe)"""
@@ -216,6 +227,7 @@ class Reference:
                                                    p.cfl_limit, p.grav_const, p.central_mass)],
                           pos0)
         L.ref_set_examine_count(p.examine_count)
+        L.ref_set_damping(C.c_float(p.damping))
         L.ref_set_scale(C.c_float(p.sim_scale), C.c_float(p.sim_scale_inv))
         L.ref_resize(n)
 
@@ -266,6 +278,15 @@ class Reference:
 
     def set_lists(self, cap, nb, nd, cnt):
         self.lib.ref_set_lists(cap, _ptr(nb), _ptr(nd), _ptr(cnt))
+
+    def boundary(self, position, vel, time_step, newpos):
+        """SPH::handleBoundaryConditions on every particle; returns (vel, newpos) copies."""
+        position = _f32(position)
+        vel = _f32(vel).copy()
+        newpos = _f32(newpos).copy()
+        self.lib.ref_boundary(position.size // 3, _ptr(position), _ptr(vel),
+                              C.c_float(time_step), _ptr(newpos))
+        return vel, newpos
 
     def energy(self):
         ke, pe = C.c_float(), C.c_float()

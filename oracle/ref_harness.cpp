@@ -249,6 +249,23 @@ void ref_set_lists(int cap, const uint32_t* neighbors, const float* dists, const
    std::memcpy(s->mSrcParticles->mNeighborCount.data(), counts, sizeof(int) * n);
 }
 
+// The reference's wall handling (src/sph.cpp:1025-1148), defined but never called by step():
+// run it for n particles.  position: old positions; vel / newpos are updated in place.
+void ref_boundary(int n, const float* position, float* vel, float time_step, float* newpos)
+{
+   SPH* s = S();
+   for (int i = 0; i < n; i++) {
+      vec3 p(position[3 * i], position[3 * i + 1], position[3 * i + 2]);
+      vec3 v(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]);
+      vec3 np(newpos[3 * i], newpos[3 * i + 1], newpos[3 * i + 2]);
+      s->handleBoundaryConditions(p, &v, time_step, &np);
+      vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z;
+      newpos[3 * i] = np.x; newpos[3 * i + 1] = np.y; newpos[3 * i + 2] = np.z;
+   }
+}
+
+void ref_set_damping(float damping) { S()->setDamping(damping); }
+
 void ref_get_energy(float* ke, float* pe)
 {
    *ke = S()->mKineticEnergyTotal;

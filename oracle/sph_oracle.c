@@ -353,6 +353,8 @@ static inline void accel_end(const sph_oracle_params* p, accel_state* s, float* 
       float g = rs[c] / d3;
       a[c] += -p->grav_const * p->central_mass * g;
    }
+   if (p->apply_gravity) /* extension: uniform gravity enters next to the point-mass term */
+      for (int c = 0; c < 3; c++) a[c] += p->gravity[c];
    dot = (a[0] * a[0]) + (a[1] * a[1]) + (a[2] * a[2]);
    if (dot > p->cfl_limit2) {
       float length = sqrtf(dot);
@@ -380,6 +382,45 @@ void oracle_accel_lists(const sph_oracle_params* p, int n, int cap, const uint32
 }
 
 /* ------------------------------------------------------------------------------------
+ * Wall reflection.  reference src/sph.cpp:1124-1148 (applyBoundary) and :1025-1121
+ * (handleBoundaryConditions).  vec3 operators are component-wise float ops; `*` between
+ * vec3 and float scales, the dot product is written out (x*nx + y*ny + z*nz). */
+static void apply_boundary(const sph_oracle_params* p, const float* position, float time_step,
+                           float* new_position, float intersection_distance, const float* normal,
+                           float* new_velocity)
+{
+   float intersection[3], reflection[3];
+   for (int c = 0; c < 3; c++)
+      intersection[c] = position[c] + (new_velocity[c] * intersection_distance);
+   float dot = new_velocity[0] * normal[0] + new_velocity[1] * normal[1] +
+               new_velocity[2] * normal[2];
+   for (int c = 0; c < 3; c++) reflection[c] = new_velocity[c] - ((normal[c] * dot) * 2.0f);
+   float remaining = time_step - intersection_distance;
+   for (int c = 0; c < 3; c++) {
+      new_velocity[c] = reflection[c];
+      new_position[c] = intersection[c] + reflection[c] * (remaining * p->damping);
+   }
+}
+
+void oracle_boundary(const sph_oracle_params* p, const float* position, float* new_velocity,
+                     float time_step, float* new_position)
+{
+   const float maxv[3] = {p->max_x, p->max_y, p->max_z};
+   for (int axis = 0; axis < 3; axis++) { /* x, then y, then z; `else if` per axis */
+      float normal[3] = {0.0f, 0.0f, 0.0f};
+      if (new_position[axis] < 0.0f) {
+         normal[axis] = 1.0f;
+         float dist = -position[axis] / new_velocity[axis];
+         apply_boundary(p, position, time_step, new_position, dist, normal, new_velocity);
+      } else if (new_position[axis] > maxv[axis]) {
+         normal[axis] = -1.0f;
+         float dist = (maxv[axis] - position[axis]) / new_velocity[axis];
+         apply_boundary(p, position, time_step, new_position, dist, normal, new_velocity);
+      }
+   }
+}
+
+/* ------------------------------------------------------------------------------------
  * A6 — integrate.  reference src/sph.cpp:937-1022 */
 void oracle_integrate(const sph_oracle_params* p, int n, float* pos, float* vel, const float* acc,
                       const float* mass, float* ke_out, float* pe_out)
@@ -397,8 +438,11 @@ void oracle_integrate(const sph_oracle_params* p, int n, float* pos, float* vel,
       float d3 = (dot + p->softening) * (dot + p->softening) * (dot + p->softening);
       for (int c = 0; c < 3; c++) {
          float a = -p->grav_const * p->central_mass * (rs[c] / d3);
+         if (p->apply_gravity) a += p->gravity[c]; /* extension, see accel_end */
          nv[c] = vh[c] + (a * dt);
       }
+      if (p->apply_walls) /* extension: the reference's own (unwired) wall handling */
+         oracle_boundary(p, pos + 3 * i, nv, dt, np);
       dot = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2];
       if (dot > 0) {
          ke += 0.5f * mass[i] * dot;

@@ -6,6 +6,43 @@
 
 #define RED_THREADS 256
 
+// SPH::applyBoundary (reference src/sph.cpp:1124-1148): reflect at a wall with unit normal
+// along `axis` (sign sgn), continue for the rest of the step scaled by mDamping.  vec3
+// operators of the reference are component-wise fp32 operations.
+__device__ __forceinline__ void apply_boundary(const PairConsts& k, const float pos[3], float dt,
+                                               float np[3], float dist, int axis, float sgn,
+                                               float nv[3])
+{
+   float normal[3] = {0.0f, 0.0f, 0.0f};
+   normal[axis] = sgn;
+   float inter[3], refl[3];
+#pragma unroll
+   for (int c = 0; c < 3; c++) inter[c] = pos[c] + (nv[c] * dist);
+   const float dot = nv[0] * normal[0] + nv[1] * normal[1] + nv[2] * normal[2];
+#pragma unroll
+   for (int c = 0; c < 3; c++) refl[c] = nv[c] - ((normal[c] * dot) * 2.0f);
+   const float remaining = dt - dist;
+#pragma unroll
+   for (int c = 0; c < 3; c++) {
+      nv[c] = refl[c];
+      np[c] = inter[c] + refl[c] * (remaining * k.damping);
+   }
+}
+
+// SPH::handleBoundaryConditions (reference src/sph.cpp:1025-1121): x, then y, then z.
+__device__ __forceinline__ void handle_boundaries(const PairConsts& k, const float pos[3],
+                                                  float nv[3], float dt, float np[3])
+{
+   const float maxv[3] = {k.max_x, k.max_y, k.max_z};
+#pragma unroll
+   for (int axis = 0; axis < 3; axis++) {
+      if (np[axis] < 0.0f)
+         apply_boundary(k, pos, dt, np, -pos[axis] / nv[axis], axis, 1.0f, nv);
+      else if (np[axis] > maxv[axis])
+         apply_boundary(k, pos, dt, np, (maxv[axis] - pos[axis]) / nv[axis], axis, -1.0f, nv);
+   }
+}
+
 // ---- integrate (reference src/sph.cpp:937-1022) -------------------------------------------------
 // "KDK as coded": half kick with the SPH acceleration, drift, then a FULL-dt kick with the
 // point-mass gravity only, evaluated at the new position.  KE/PE contributions are reduced per
@@ -28,11 +65,11 @@ k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* 
       const float vhx = v.x + (a.x * dt * 0.5f);
       const float vhy = v.y + (a.y * dt * 0.5f);
       const float vhz = v.z + (a.z * dt * 0.5f);
-      const float nx = x.x + (vhx * pos_dt);
-      const float ny = x.y + (vhy * pos_dt);
-      const float nz = x.z + (vhz * pos_dt);
+      const float nx0 = x.x + (vhx * pos_dt);
+      const float ny0 = x.y + (vhy * pos_dt);
+      const float nz0 = x.z + (vhz * pos_dt);
 
-      float rsx = (nx - k.cx), rsy = (ny - k.cy), rsz = (nz - k.cz);
+      float rsx = (nx0 - k.cx), rsy = (ny0 - k.cy), rsz = (nz0 - k.cz);
       if (!UNIT_SCALE) {
          rsx *= k.sim_scale;
          rsy *= k.sim_scale;
@@ -43,9 +80,23 @@ k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* 
       const float ds = dot + k.softening;
       const float d3 = ds * ds * ds;
       const float gm = -k.grav_const * k.central_mass;
-      const float nvx = vhx + ((gm * (rsx / d3)) * dt);
-      const float nvy = vhy + ((gm * (rsy / d3)) * dt);
-      const float nvz = vhz + ((gm * (rsz / d3)) * dt);
+      float agx = gm * (rsx / d3), agy = gm * (rsy / d3), agz = gm * (rsz / d3);
+      if (k.apply_gravity) { // extension, as in accel_end
+         agx += k.gx;
+         agy += k.gy;
+         agz += k.gz;
+      }
+      float nvx = vhx + (agx * dt);
+      float nvy = vhy + (agy * dt);
+      float nvz = vhz + (agz * dt);
+      float nx = nx0, ny = ny0, nz = nz0;
+      if (k.apply_walls) { // extension: the reference's own (unwired) wall handling
+         const float pos[3] = {x.x, x.y, x.z};
+         float nv[3] = {nvx, nvy, nvz}, np[3] = {nx, ny, nz};
+         handle_boundaries(k, pos, nv, dt, np);
+         nvx = nv[0]; nvy = nv[1]; nvz = nv[2];
+         nx = np[0]; ny = np[1]; nz = np[2];
+      }
 
       dot = nvx * nvx + nvy * nvy + nvz * nvz;
       if (dot > 0) {

@@ -139,6 +139,11 @@ __device__ __forceinline__ float4 accel_end(const PairConsts& k, const AccelStat
    ax += gm * (rsx / d3);
    ay += gm * (rsy / d3);
    az += gm * (rsz / d3);
+   if (k.apply_gravity) { // extension: uniform gravity enters next to the point-mass term
+      ax += k.gx;
+      ay += k.gy;
+      az += k.gz;
+   }
 
    dot = (ax * ax) + (ay * ay) + (az * az);
    if (dot > k.cfl_limit2) {

@@ -53,6 +53,11 @@ struct PairConsts {
    float grav_const, central_mass, cx, cy, cz, softening;
    float cfl_limit, cfl_limit2;
    float dt, sim_scale_inv;
+   // dam-break extensions (0 = shipped behaviour)
+   float gx, gy, gz;         // mGravity
+   float damping;            // mDamping
+   float max_x, max_y, max_z; // mMaxX/Y/Z
+   int apply_gravity, apply_walls;
 };
 
 struct sph_hip_context {

@@ -50,6 +50,15 @@ PairConsts pair_consts(const sph_hip_params& p)
    k.cfl_limit2 = p.cfl_limit2;
    k.dt = p.time_step;
    k.sim_scale_inv = p.sim_scale_inv;
+   k.gx = p.gravity[0];
+   k.gy = p.gravity[1];
+   k.gz = p.gravity[2];
+   k.damping = p.damping;
+   k.max_x = p.max_x;
+   k.max_y = p.max_y;
+   k.max_z = p.max_z;
+   k.apply_gravity = p.apply_gravity;
+   k.apply_walls = p.apply_walls;
    return k;
 }
 

@@ -33,6 +33,7 @@ class SphParams(C.Structure):
         ("examine_count", C.c_int32),
         ("full_cells_x", C.c_int32), ("full_cells_y", C.c_int32), ("full_cells_z", C.c_int32),
         ("full_cell_inv", C.c_float),
+        ("apply_gravity", C.c_int32), ("apply_walls", C.c_int32),
     ]
 
     def copy(self):
