@@ -104,6 +104,14 @@ def load_library(path=None):
     if _LIB is not None and path is None:
         return _LIB
     path = path or library_path()
+    # Plumbing: when PyTorch is installed it must bring up ITS ROCm runtime before this library
+    # touches HIP — two independently initialised HIP runtimes in one process leave the second
+    # one without a device ("no ROCm-capable device is detected").  torch is only imported, never
+    # used here; the C++ host (integration/) has no such concern.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise SphHipError(
             "libsph_hip.so is missing (%s): build it with "
