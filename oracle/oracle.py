@@ -231,9 +231,10 @@ class Reference:
         L.ref_set_scale(C.c_float(p.sim_scale), C.c_float(p.sim_scale_inv))
         L.ref_resize(n)
 
-    def constants(self):
+    def constants(self, fresh=True):
+        """fresh: from a newly constructed SPH (the constructor's own values)"""
         out = np.zeros(32, np.float32)
-        self.lib.ref_get_constants(_ptr(out))
+        self.lib.ref_get_constants2(_ptr(out), 1 if fresh else 0)
         return out
 
     def init_sphere(self):

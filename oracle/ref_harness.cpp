@@ -133,9 +133,14 @@ void ref_set_physics(float rho0, float stiffness, float viscosity, float dt, flo
 
 // Dump the constants the constructor derived (src/sph.cpp:46-98) so the restatement can be
 // checked against them.  out[] needs 32 floats.
-void ref_get_constants(float* out)
+// fresh != 0: read them from a newly constructed object (what SPH::SPH() derives), independent
+// of anything the harness has overridden on the shared one
+void ref_get_constants2(float* out, int fresh);
+void ref_get_constants(float* out) { ref_get_constants2(out, 0); }
+
+void ref_get_constants2(float* out, int fresh)
 {
-   SPH* s = S();
+   SPH* s = fresh ? new SPH() : S();
    int k = 0;
    out[k++] = s->mH;
    out[k++] = s->mH2;
@@ -169,6 +174,7 @@ void ref_get_constants(float* out)
    out[k++] = (float)s->mGridCellsX;
    out[k++] = (float)s->mGridCellsY;
    out[k++] = (float)s->mGridCellsZ;
+   if (fresh) delete s;
 }
 
 // ---- state in / out ----------------------------------------------------------------
