@@ -36,6 +36,9 @@
 #define NLIST_WORDS (NLIST_CAP / 2 + 1)
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
 #define DENSITY_UNROLL 6
+#ifndef APPEND_POPS
+#define APPEND_POPS 4     // accepted candidates appended per trip of the append loop
+#endif
 #define ACCEL_UNROLL 8
 // queue entry: segment id << 12 | tile index (TILE_CAP + 32 <= 4096)
 #define QUEUE_TBITS 12
@@ -293,17 +296,20 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          // a register, an odd one completes a 32-bit word and stores it (half the scattered
          // stores); words past NLIST_CAP all land in the spare row (workgroup flagged, redone)
          while (__any(mask != 0u)) {
-            if (mask != 0u) {
-               const uint32_t bit = (uint32_t)__builtin_ctz(mask);
-               mask &= mask - 1u;
-               const uint32_t entry = kbits | ((uint32_t)t0 + bit);
-               if (count & 1) {
-                  const uint32_t row = count < NLIST_CAP ? (uint32_t)count >> 1 : (uint32_t)(NLIST_CAP / 2);
-                  list_block[row * TILE_THREADS + (uint32_t)tid] = hold | (entry << 16);
-               } else {
-                  hold = entry;
+#pragma unroll
+            for (int rep = 0; rep < APPEND_POPS; rep++) {   // several pops per trip: less loop control
+               if (mask != 0u) {
+                  const uint32_t bit = (uint32_t)__builtin_ctz(mask);
+                  mask &= mask - 1u;
+                  const uint32_t entry = kbits | ((uint32_t)t0 + bit);
+                  if (count & 1) {
+                     const uint32_t row = count < NLIST_CAP ? (uint32_t)count >> 1 : (uint32_t)(NLIST_CAP / 2);
+                     list_block[row * TILE_THREADS + (uint32_t)tid] = hold | (entry << 16);
+                  } else {
+                     hold = entry;
+                  }
+                  count++;
                }
-               count++;
             }
          }
       }
