@@ -169,7 +169,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
-    if rank == 0:
+    # The library is built in-tree by __graft_entry__.build(); only a missing one is compiled
+    # here, and only when no other rank could be loading it at the same time.
+    if not os.path.exists(S.library_path()):
+        if world > 1:
+            raise SystemExit("libsph_hip.so is missing: run `python -c 'import __graft_entry__ as "
+                             "g; g.build()'` before a multi-rank launch")
         S.build_library()
     n = args.particles
     if world > 1:
