@@ -110,7 +110,9 @@ void SPH::run()
 {
    int stepCount = 0;
    mkdir("out", 0777);
-   std::ofstream energy("out/energy.txt"), timing("out/timing.txt");
+   std::ofstream energy("out/energy.txt"), timing("out/timing.txt"), momentum("out/angularmomentum.txt");
+   std::ofstream neighbors("out/neighbors.txt");
+   momentum << "Step, Angular Momentum" << std::endl;
    energy << "Step, Kinetic Energy, Potential Energy, Total Energy" << std::endl;
    timing << "Step, Voxelize, Find Neighbors, Compute Density, Compute Pressure, "
              "Compute Acceleration, Integrate" << std::endl;
@@ -122,6 +124,10 @@ void SPH::run()
       timing << stepCount << ", " << timeVoxelize << ", " << timeFindNeighbors << ", "
              << timeComputeDensity << ", " << timeComputePressure << ", " << timeComputeAcceleration
              << ", " << timeIntegrate << std::endl;
+      momentum << stepCount << ", " << mAngularMomentumTotal.length() << std::endl;
+      int32_t avg = 0, mx = 0, mn = 0;   // the line step() appends to out/neighbors.txt (:232)
+      check(sph_hip_get_neighbor_stats(g_ctx, &avg, &mx, &mn), "sph_hip_get_neighbor_stats");
+      neighbors << avg << ", " << mx << ", " << mn << std::endl;
       stepCount++;
    }
 }

@@ -72,3 +72,57 @@ def dense_block(n, lo=(1.0, 1.0, 1.0), hi=(2.2, 2.2, 2.2), seed=7, speed=0.5):
     vel = (box_fill(n, (-speed,) * 3, (speed,) * 3, seed + 1)).astype(np.float32)
     mass = np.ones(n, np.float32)
     return p, pos, vel, mass
+
+
+def reference_sphere(n, params=None):
+    """The reference's default scene (src/sph.cpp:361-425): srand(42), rejection-sampled points
+    within radius 2 of the box centre, tangential velocity 20*(dist + h/2)^-0.5 in the x-z plane,
+    small random v_y.  Uses the C library's own rand()/atan2f/sinf/cosf/pow through ctypes, so on
+    a glibc system the arrays are bit-identical to what `SPH::SPH()` builds with -DM=n/1024.
+
+    Returns (params, pos[3n], vel[3n], mass[n]).  Not thread-safe (libc rand() state)."""
+    import ctypes as C
+    import ctypes.util
+    libc = C.CDLL(ctypes.util.find_library("c") or "libc.so.6")
+    libm = C.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libc.rand.restype = C.c_int
+    for name in ("atan2f",):
+        getattr(libm, name).restype = C.c_float
+        getattr(libm, name).argtypes = [C.c_float, C.c_float]
+    for name in ("sinf", "cosf", "sqrtf"):
+        getattr(libm, name).restype = C.c_float
+        getattr(libm, name).argtypes = [C.c_float]
+    libm.pow.restype = C.c_double
+    libm.pow.argtypes = [C.c_double, C.c_double]
+    p = params.copy() if params is not None else default_params()
+    f32 = np.float32
+    rand_max = f32(2147483647.0)           # (float)RAND_MAX
+    ext = [f32(p.cells_x) * f32(p.htimes2), f32(p.cells_y) * f32(p.htimes2),
+           f32(p.cells_z) * f32(p.htimes2)]
+    cells = [f32(p.cells_x), f32(p.cells_y), f32(p.cells_z)]
+    centre = [f32(p.max_x) * f32(0.5), f32(p.max_y) * f32(0.5), f32(p.max_z) * f32(0.5)]
+    half_h = float(f32(p.hscaled)) * 0.5   # double, as in `mHScaled*0.5`
+    pos = np.zeros(3 * n, f32)
+    vel = np.zeros(3 * n, f32)
+    libc.srand(42)
+    for i in range(n):
+        while True:
+            c = []
+            for a in range(3):
+                v = f32(libc.rand()) / rand_max
+                v = v * ext[a]
+                if v == cells[a]:
+                    v = v - f32(0.00001)
+                c.append(f32(v))
+            d = [f32(c[a] - centre[a]) for a in range(3)]
+            dist = f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
+            dist = f32(libm.sqrtf(dist))
+            if not dist > f32(2.0):
+                break
+        pos[3 * i:3 * i + 3] = c
+        phi = f32(libm.atan2f(f32(c[2] - centre[2]), f32(c[0] - centre[0])))
+        amp = 20.0 * libm.pow(float(dist) + half_h, -0.5)          # double
+        vel[3 * i] = f32(amp * float(f32(-libm.sinf(phi))))
+        vel[3 * i + 2] = f32(amp * float(f32(libm.cosf(phi))))
+        vel[3 * i + 1] = f32(f32(f32(libc.rand()) / rand_max) * f32(0.5)) - f32(0.25)
+    return p, pos, vel, np.ones(n, f32)

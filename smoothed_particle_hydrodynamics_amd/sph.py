@@ -210,6 +210,29 @@ class SPH:
         self._check(self._lib.sph_hip_run(self._ctx, int(steps)), "sph_hip_run")
         self._mirror_fresh = False
 
+    def runToFiles(self, total_steps, outdir="out"):
+        """SPH::run() (reference src/sph.cpp:149-187, 203, 232): `total_steps + 1` steps, one line
+        per step in energy.txt / angularmomentum.txt / timing.txt / neighbors.txt with the
+        reference's headers and column order.  Differences: times are fractional milliseconds
+        (the reference truncates to int), KE/PE are summed in a fixed order in f64."""
+        import os
+        os.makedirs(outdir, exist_ok=True)
+        with open(os.path.join(outdir, "energy.txt"), "w") as fe, \
+                open(os.path.join(outdir, "angularmomentum.txt"), "w") as fl, \
+                open(os.path.join(outdir, "timing.txt"), "w") as ft, \
+                open(os.path.join(outdir, "neighbors.txt"), "w") as fn:
+            fe.write("Step, Kinetic Energy, Potential Energy, Total Energy\n")
+            fl.write("Step, Angular Momentum\n")
+            ft.write("Step, Voxelize, Find Neighbors, Compute Density, Compute Pressure, "
+                     "Compute Acceleration, Integrate\n")
+            for s in range(int(total_steps) + 1):
+                self.step()
+                ke, pe = self.energy()
+                fe.write("%d, %.9g, %.9g, %.9g\n" % (s, ke, pe, np.float32(ke) + np.float32(pe)))
+                fl.write("%d, 0\n" % s)          # mAngularMomentumTotal is never accumulated
+                ft.write("%d, %s\n" % (s, ", ".join("%.4f" % v for v in self.elapsed())))
+                fn.write("%d, %d, %d\n" % self.neighborStats())
+
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
 
