@@ -185,11 +185,23 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
 // ---- 3. scatter -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
-          const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
-          uint32_t* __restrict__ perm)
+          const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
+          uint32_t* __restrict__ perm, int cells_per_plane, int ncells, int own_lo, int own_hi,
+          int sum_lo, int sum_hi)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i < meta[META_N_IN]) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
+   const int n_in = meta[META_N_IN];
+   if (i < n_in) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
+   if (i == 0) {
+      // Sorted ranges of the slab (kept out of a launch of their own: a kernel boundary costs
+      // more than this does): live entries, owned planes [lo, hi), density planes one wider.
+      // Planes are LOCAL indices.  Nothing in this launch reads these words.
+      meta[META_N_LIVE] = (int)cell_start[ncells];
+      meta[META_OWN_BEGIN] = (int)cell_start[own_lo * cells_per_plane];
+      meta[META_OWN_END] = (int)cell_start[own_hi * cells_per_plane];
+      meta[META_SUM_BEGIN] = (int)cell_start[sum_lo * cells_per_plane];
+      meta[META_SUM_END] = (int)cell_start[sum_hi * cells_per_plane];
+   }
 }
 
 // ---- 4a. REF: ascending-index order inside each cell ---------------------------------------
@@ -236,19 +248,4 @@ k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ ke
    }
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;
-}
-
-// ---- 5. sorted ranges of a slab ----------------------------------------------------------------
-// After the scan: how many entries are live, which sorted range is owned (planes [lo, hi)) and
-// which range needs densities (one more plane on each side).  Planes are LOCAL indices.
-__global__ void k_slab_ranges(const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
-                              int cells_per_plane, int ncells, int own_lo, int own_hi, int sum_lo,
-                              int sum_hi)
-{
-   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-   meta[META_N_LIVE] = (int)cell_start[ncells];
-   meta[META_OWN_BEGIN] = (int)cell_start[own_lo * cells_per_plane];
-   meta[META_OWN_END] = (int)cell_start[own_hi * cells_per_plane];
-   meta[META_SUM_BEGIN] = (int)cell_start[sum_lo * cells_per_plane];
-   meta[META_SUM_END] = (int)cell_start[sum_hi * cells_per_plane];
 }

@@ -37,24 +37,17 @@ __device__ __forceinline__ void row_ranges(const CellGrid& g, const uint32_t* __
    }
 }
 
-// ---- density, untiled: one thread per particle, candidates read through L1/L2.  Used for
-// workgroups whose LDS tile would overflow (full_tiled.h) and as an independent cross-check.
+// ---- density, untiled: one thread per particle, candidates read through L1/L2 -------------------
+// Used for workgroups whose LDS tile or neighbour lists would overflow (called inline from the
+// tiled kernels of full_tiled.h), for SPH_HIP_UNTILED=1, and as an independent cross-check.
 template <bool UNIT_SCALE>
-__global__ void __launch_bounds__(256)
-k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
-               const float4* __restrict__ velp, const int32_t* __restrict__ meta, CellGrid g,
-               PairConsts k, float* __restrict__ rho, float4* __restrict__ velB,
-               float* __restrict__ auxc, int32_t* __restrict__ ncount,
-               const uint32_t* __restrict__ redo)
+__device__ __forceinline__ void density_untiled(int p, const float4* __restrict__ posm,
+                                                const uint32_t* __restrict__ cell_start,
+                                                const float4* __restrict__ velp, const CellGrid& g,
+                                                const PairConsts& k, float* __restrict__ rho,
+                                                float4* __restrict__ velB, float* __restrict__ auxc,
+                                                int32_t* __restrict__ ncount)
 {
-   // redo == nullptr: every workgroup (SPH_HIP_UNTILED=1).  Otherwise the fallback of the tiled
-   // kernel: redo[0] = number of 256-particle workgroups it gave up on (tile or neighbour list
-   // did not fit), redo[1..] = their indices; a small grid walks that list.
-   const int nwork = redo ? (int)redo[0] : (int)gridDim.x;
-   for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
-   const int wg = redo ? (int)redo[1 + w] : w;
-   const int p = meta[META_SUM_BEGIN] + wg * blockDim.x + threadIdx.x;
-   if (p >= meta[META_SUM_END]) continue;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
@@ -63,9 +56,13 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
 
    float density = 0.0f;
    int count = 0;
-#pragma unroll
+#pragma unroll 1
    for (int row = 0; row < 9; row++) {
-      for (uint32_t q = r.s[row]; q < r.e[row]; q++) {
+      const uint32_t s = row == 0 ? r.s[0] : row == 1 ? r.s[1] : row == 2 ? r.s[2] : row == 3 ? r.s[3]
+                       : row == 4 ? r.s[4] : row == 5 ? r.s[5] : row == 6 ? r.s[6] : row == 7 ? r.s[7] : r.s[8];
+      const uint32_t e = row == 0 ? r.e[0] : row == 1 ? r.e[1] : row == 2 ? r.e[2] : row == 3 ? r.e[3]
+                       : row == 4 ? r.e[4] : row == 5 ? r.e[5] : row == 6 ? r.e[6] : row == 7 ? r.e[7] : r.e[8];
+      for (uint32_t q = s; q < e; q++) {
          if (q == (uint32_t)p) continue;
          const float4 pj = posm[q];
          float dx, dy, dz;
@@ -84,25 +81,30 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
    velB[p] = make_float4(v.x, v.y, v.z, bc.x);
    auxc[p] = bc.y;
    ncount[p] = count;
-   }
+}
+
+template <bool UNIT_SCALE>
+__global__ void __launch_bounds__(256)
+k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
+               const float4* __restrict__ velp, const int32_t* __restrict__ meta, CellGrid g,
+               PairConsts k, float* __restrict__ rho, float4* __restrict__ velB,
+               float* __restrict__ auxc, int32_t* __restrict__ ncount)
+{
+   const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_SUM_END]) return;
+   density_untiled<UNIT_SCALE>(p, posm, cell_start, velp, g, k, rho, velB, auxc, ncount);
 }
 
 // ---- acceleration, untiled ------------------------------------------------------------------------
 template <bool UNIT_SCALE>
-__global__ void __launch_bounds__(256)
-k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
-             const float* __restrict__ rho, const float* __restrict__ auxc,
-             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
-             PairConsts k, float4* __restrict__ acc, const uint32_t* __restrict__ redo)
+__device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ posm,
+                                              const float4* __restrict__ velB,
+                                              const float* __restrict__ rho,
+                                              const float* __restrict__ auxc,
+                                              const uint32_t* __restrict__ cell_start,
+                                              const CellGrid& g, const PairConsts& k,
+                                              float4* __restrict__ acc)
 {
-   // same scheme as k_full_density: all workgroups, or the tiled pass's give-up list
-   const int nwork = redo ? (int)redo[0] : (int)gridDim.x;
-   for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
-   const int wg = redo ? (int)redo[1 + w] : w;
-   // same workgroup -> particle mapping as the tiled kernels (from the density range); the
-   // acceleration is only needed for owned particles
-   const int p = meta[META_SUM_BEGIN] + wg * blockDim.x + threadIdx.x;
-   if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) continue;
    const float4 pi = posm[p];
    int cx, cy, cz;
    cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
@@ -111,9 +113,13 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
 
    AccelState s;
    accel_begin(k, s, pi, velB[p], rho[p]);
-#pragma unroll
+#pragma unroll 1
    for (int row = 0; row < 9; row++) {
-      for (uint32_t q = r.s[row]; q < r.e[row]; q++) {
+      const uint32_t b = row == 0 ? r.s[0] : row == 1 ? r.s[1] : row == 2 ? r.s[2] : row == 3 ? r.s[3]
+                       : row == 4 ? r.s[4] : row == 5 ? r.s[5] : row == 6 ? r.s[6] : row == 7 ? r.s[7] : r.s[8];
+      const uint32_t e = row == 0 ? r.e[0] : row == 1 ? r.e[1] : row == 2 ? r.e[2] : row == 3 ? r.e[3]
+                       : row == 4 ? r.e[4] : row == 5 ? r.e[5] : row == 6 ? r.e[6] : row == 7 ? r.e[7] : r.e[8];
+      for (uint32_t q = b; q < e; q++) {
          if (q == (uint32_t)p) continue;
          const float4 pj = posm[q];
          float dx, dy, dz;
@@ -127,5 +133,18 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
       }
    }
    acc[p] = accel_end<UNIT_SCALE>(k, s);
-   }
+}
+
+template <bool UNIT_SCALE>
+__global__ void __launch_bounds__(256)
+k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
+             const float* __restrict__ rho, const float* __restrict__ auxc,
+             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
+             PairConsts k, float4* __restrict__ acc)
+{
+   // same workgroup -> particle mapping as the tiled kernels (from the density range); the
+   // acceleration is only needed for owned particles
+   const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) return;
+   accel_untiled<UNIT_SCALE>(p, posm, velB, rho, auxc, cell_start, g, k, acc);
 }

@@ -19,8 +19,8 @@
 // rescaled inside that loop (src/sph.cpp:880-882), so each particle's sum stays on one lane;
 // nothing is reduced across lanes.
 //
-// Workgroups whose tile would not fit (very dense regions) are flagged and redone by the
-// untiled kernels of full_kernels.h — same results, slower.
+// Workgroups whose tile would not fit (very dense regions) are flagged and run the untiled
+// code of full_kernels.h inline — same results, slower, no extra launch.
 #pragma once
 
 #include "full_kernels.h"
@@ -77,10 +77,9 @@ struct TileLds {
 __global__ void __launch_bounds__(256)
 k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
             const int32_t* __restrict__ meta, int range, CellGrid g, int ntiles,
-            TileDesc* __restrict__ desc, uint32_t* __restrict__ redo)
+            TileDesc* __restrict__ desc)
 {
    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-   if (tile == 0) redo[0] = 0u;  // the tiled density pass appends the workgroups it gives up on
    if (tile >= ntiles) return;
    const int begin = meta[range], end = meta[range + 1];
    const int p0 = begin + tile * TILE_THREADS;
@@ -210,7 +209,7 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
 // TEST appends every accepted neighbour (self excluded), in canonical order, to the lane's
 // column of the workgroup's list block in global memory; SUM then walks that list once.  The
 // list doubles as the input of the acceleration pass.  A workgroup in which some particle has
-// more than NLIST_CAP neighbours gives up (flag) and is redone by the untiled kernel.
+// more than NLIST_CAP neighbours gives up (flag) and runs the untiled code inline instead.
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
 __global__ void __launch_bounds__(TILE_THREADS, 4)
 k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
@@ -218,8 +217,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                      CellGrid g, PairConsts k, float* __restrict__ rho_out,
                      float4* __restrict__ velB_out, float* __restrict__ auxc_out,
                      int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
-                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
-                     uint32_t* __restrict__ redo)
+                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow)
 {
    __shared__ __attribute__((aligned(16))) TileLds L;
    __shared__ int list_overflow;
@@ -239,11 +237,11 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    if (live) pi = posm[p];
    tile_desc_load(desc, L);
    if (L.desc.total > TILE_CAP) {
-      // tile does not fit: hand the workgroup to the untiled kernels
-      if (tid == 0) {
-         nlist_overflow[blockIdx.x] = 1u;
-         redo[1 + atomicAdd(&redo[0], 1u)] = blockIdx.x;
-      }
+      // tile does not fit: this workgroup computes its particles the untiled way, right here
+      // (a separate fallback launch costs ~55 us per step even when it has nothing to do)
+      if (tid == 0) nlist_overflow[blockIdx.x] = 1u;
+      if (live) density_untiled<UNIT_SCALE>(p, posm, cell_start, velp, g, k, rho_out, velB_out,
+                                            auxc_out, ncount);
       return;
    }
    RowRanges r;
@@ -319,11 +317,12 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    if (count > NLIST_CAP) list_overflow = 1;
    __syncthreads();
    const int give_up = list_overflow;
-   if (tid == 0) {
-      nlist_overflow[blockIdx.x] = (uint32_t)give_up;
-      if (give_up) redo[1 + atomicAdd(&redo[0], 1u)] = blockIdx.x;
+   if (tid == 0) nlist_overflow[blockIdx.x] = (uint32_t)give_up;
+   if (give_up) {  // a list did not fit: redo the workgroup the untiled way
+      if (live) density_untiled<UNIT_SCALE>(p, posm, cell_start, velp, g, k, rho_out, velB_out,
+                                            auxc_out, ncount);
+      return;
    }
-   if (give_up) return;  // a list did not fit: the untiled kernels redo this workgroup
 
    // SUM: one pass over the list, in canonical order
    float density = 0.0f;
@@ -382,8 +381,9 @@ template <bool UNIT_SCALE, bool UNIFORM_MASS>
 __global__ void __launch_bounds__(TILE_THREADS, 3)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
                    const float* __restrict__ rho, const float* __restrict__ auxc,
-                   const int32_t* __restrict__ ncount, const int32_t* __restrict__ meta,
-                   PairConsts k, float4* __restrict__ acc, const TileDesc* __restrict__ desc,
+                   const int32_t* __restrict__ ncount, const uint32_t* __restrict__ cell_start,
+                   const int32_t* __restrict__ meta, CellGrid g, PairConsts k,
+                   float4* __restrict__ acc, const TileDesc* __restrict__ desc,
                    const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow)
 {
    __shared__ __attribute__((aligned(16))) AccelLds L;
@@ -392,10 +392,15 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
    const int tid = threadIdx.x;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
-   // nothing to do for workgroups past the range or made of ghosts only; workgroups whose tile
-   // or lists overflowed are redone by the untiled kernel
+   // nothing to do for workgroups past the range or made of ghosts only
    if (p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) return;
-   if (nlist_overflow[blockIdx.x]) return;  // tile or lists did not fit: redone untiled
+   if (nlist_overflow[blockIdx.x]) {
+      // the density pass gave up on this workgroup's tile or lists: untiled path, inline
+      const int pp = p0 + tid;
+      if (pp < end && pp >= ob && pp < oe)
+         accel_untiled<UNIT_SCALE>(pp, posm, velB, rho, auxc, cell_start, g, k, acc);
+      return;
+   }
    int my_cnt = 0;  // requested before the tile: the lane permutation below needs it
    {
       const int pp = p0 + tid;

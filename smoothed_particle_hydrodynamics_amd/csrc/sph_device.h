@@ -106,7 +106,6 @@ struct sph_hip_context {
    struct TileDesc* tile_desc = nullptr; // per 256-particle workgroup: LDS tile layout
    uint32_t* nlist = nullptr;            // neighbour lists density pass -> acceleration pass
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
-   uint32_t* redo = nullptr;             // [0] = count, [1..] = workgroups redone untiled
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
 

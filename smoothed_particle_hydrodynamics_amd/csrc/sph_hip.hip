@@ -20,9 +20,6 @@
 
 namespace {
 
-// grid of the untiled kernels when they only walk the tiled pass's give-up list
-constexpr int REDO_GRID = 1024;
-
 std::string g_create_error;
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
@@ -79,7 +76,7 @@ void free_all(sph_hip_context* ctx)
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
                    ctx->scan_part, ctx->rho, ctx->velB, ctx->auxc, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
                    ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta, ctx->nlist,
-                   ctx->nlist_overflow, ctx->redo};
+                   ctx->nlist_overflow};
    for (void* q : ptrs)
       if (q) (void)hipFree(q);
    if (ctx->ev) {
@@ -131,10 +128,9 @@ int launch_cell_build(sph_hip_context* ctx)
    const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
    const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
    const int sum_hi = own_hi + 1 > g.nz ? g.nz : own_hi + 1;
-   hipLaunchKernelGGL(k_slab_ranges, dim3(1), dim3(1), 0, st, ctx->cell_start, ctx->meta,
-                      g.nx * g.ny, g.ncells, own_lo, own_hi, sum_lo, sum_hi);
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
-                      ctx->cell_start, ctx->meta, ctx->perm);
+                      ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
+                      sum_lo, sum_hi);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
                          ctx->cell_start, ctx->meta, ctx->order);
@@ -144,9 +140,9 @@ int launch_cell_build(sph_hip_context* ctx)
                          ctx->cell_start, ctx->meta, g.ncells, ctx->posm[cur], ctx->velp[cur],
                          ctx->posm[nxt], ctx->velp[nxt]);
       ctx->cur = nxt;
-      // the live set is now compacted at the front of the new buffers
-      hipLaunchKernelGGL(k_slab_set_n_in, dim3(1), dim3(1), 0, st, ctx->meta,
-                         (const SlabMsg*)nullptr, (const SlabMsg*)nullptr, ctx->capacity, 0, 0);
+      // The live set is now compacted at the front of the new buffers.  meta[N_IN] still holds
+      // this build's input count: without an exchange nothing was dropped (n_live == n_in), and
+      // with one, sph_hip_slab_unpack resets it to n_live before appending.
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -171,7 +167,7 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
    hipLaunchKernelGGL((k_full_density_tiled<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,         \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
                       ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
-                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, ctx->redo)
+                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -184,8 +180,8 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
 #define SPH_GO(U, M)                                                                             \
    hipLaunchKernelGGL((k_full_accel_lists<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,           \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
-                      ctx->ncount, ctx->meta, k, ctx->acc, ctx->tile_desc, ctx->nlist,           \
-                      ctx->nlist_overflow)
+                      ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
+                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -204,26 +200,21 @@ int launch_density(sph_hip_context* ctx)
                          ctx->nb, ctx->nd, ctx->ncount, n, ctx->prm.examine_count, k, ctx->rho);
    } else {
       const bool unit = unit_scale(ctx->prm);
-      const uint32_t* redo = nullptr;
-      int ublocks = blocks;
       if (ctx->use_tiled) {
-         redo = ctx->redo;
-         ublocks = blocks < REDO_GRID ? blocks : REDO_GRID;
+         static_assert(sizeof(TileDesc) == 20 * sizeof(int), "TileDesc is 20 ints");
          hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
-                            ctx->grid, blocks, ctx->tile_desc, ctx->redo);
-         launch_density_tiled(ctx, unit, blocks, k);
+                            ctx->grid, blocks, ctx->tile_desc);
+         launch_density_tiled(ctx, unit, blocks, k);  // give-up workgroups fall back inline
+      } else if (unit) {                               // SPH_HIP_UNTILED=1: untiled everywhere
+         hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
+                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount);
+      } else {
+         hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
+                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount);
       }
-      // untiled: everything (SPH_HIP_UNTILED=1), or a small grid walking the tiled pass's
-      // give-up list (usually empty)
-      if (unit)
-         hipLaunchKernelGGL(k_full_density<true>, dim3(ublocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
-                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, redo);
-      else
-         hipLaunchKernelGGL(k_full_density<false>, dim3(ublocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
-                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount, redo);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -241,22 +232,18 @@ int launch_accel(sph_hip_context* ctx)
                          ctx->prm.examine_count, k, ctx->acc);
    } else {
       const bool unit = unit_scale(ctx->prm);
-      const uint32_t* redo = nullptr;
-      int ublocks = blocks;
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         redo = ctx->redo;
-         ublocks = blocks < REDO_GRID ? blocks : REDO_GRID;
          launch_accel_lists(ctx, unit, blocks, k);
+      } else if (unit) {
+         hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
+                            ctx->meta, ctx->grid, k, ctx->acc);
+      } else {
+         hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
+                            ctx->meta, ctx->grid, k, ctx->acc);
       }
-      if (unit)
-         hipLaunchKernelGGL(k_full_accel<true>, dim3(ublocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                            ctx->meta, ctx->grid, k, ctx->acc, redo);
-      else
-         hipLaunchKernelGGL(k_full_accel<false>, dim3(ublocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                            ctx->meta, ctx->grid, k, ctx->acc, redo);
    }
    SPH_TRY(hipGetLastError());
    return SPH_HIP_OK;
@@ -456,8 +443,6 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
       CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS));
       CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
-      CREATE_TRY(dev_alloc(&ctx->redo, (size_t)div_up(capacity, TILE_THREADS) + 2));
-      CREATE_TRY(hipMemsetAsync(ctx->redo, 0, sizeof(uint32_t), ctx->stream));
       if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
    } else {
       CREATE_TRY(dev_alloc(&ctx->order, cap));
