@@ -73,7 +73,8 @@ struct TileLds {
 };
 
 // One thread per workgroup-to-be: the 9 row segments (cells c_first-1 .. c_last+1 of every
-// (dz,dy) row, as linear cell-id ranges) of the 256 particles starting at tile*256.
+// (dz,dy) row, as linear cell-id ranges) of the 256 particles starting at tile*256, as ranges
+// of the sorted arrays plus their placement in the LDS tile.
 __global__ void __launch_bounds__(256)
 k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
             const int32_t* __restrict__ meta, int range, CellGrid g, int ntiles,
@@ -104,12 +105,29 @@ k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_s
          len[k] = (int)cell_start[hi + 1] - G[k];
       }
    }
-   int run = 0;
+   // Segments come in ascending sorted position.  Where consecutive ones overlap or touch (short
+   // rows: a 256-particle span then covers several rows, and the dy = -1, 0, +1 segments of a
+   // plane are nearly the same range) they share tile storage: same index shift D, and only the
+   // part past the previous segment's end is new.  B[k] = first tile index of segment k's new
+   // part, so "tile index t in [B[k], B[k+1])  <->  sorted index t - D[k]" holds for the loader.
+   int run = 0, chain_end = -1, chain_d = 0;
 #pragma unroll
    for (int k = 0; k < 9; k++) {
       d.B[k] = run;
-      d.D[k] = run - G[k];
-      run += len[k];
+      if (len[k] == 0) {          // nothing to load, no lane range refers to it
+         d.D[k] = run - G[k];
+      } else if (G[k] <= chain_end) {
+         const int seg_end = G[k] + len[k];
+         d.D[k] = chain_d;
+         if (seg_end > chain_end) {
+            run += seg_end - chain_end;
+            chain_end = seg_end;
+         }
+      } else {
+         d.D[k] = chain_d = run - G[k];
+         run += len[k];
+         chain_end = G[k] + len[k];
+      }
    }
    d.total = run;
    d.pad = 0;

@@ -268,6 +268,17 @@ int launch_integrate(sph_hip_context* ctx)
    return SPH_HIP_OK;
 }
 
+// Phase boundary k of a timed step is marked by event phase_event(ctx, k) of the step's ring
+// slot.  An event record is a barrier packet (several microseconds on the stream), so a boundary
+// with no launch before it shares the previous boundary's event: FULL mode has no separate
+// neighbour search, and computePressure is a no-op in the reference (src/sph.cpp:253-263).
+inline int phase_event(const sph_hip_context* ctx, int k)
+{
+   if (k == 4) return 3;
+   if (k == 2 && ctx->mode == SPH_HIP_MODE_FULL) return 1;
+   return k;
+}
+
 int step_impl(sph_hip_context* ctx, bool timed)
 {
    int rc;
@@ -277,11 +288,9 @@ int step_impl(sph_hip_context* ctx, bool timed)
    if ((rc = launch_cell_build(ctx))) return rc;
    if (timed) SPH_TRY(hipEventRecord(ev[1], st));
    if ((rc = launch_find_neighbors(ctx))) return rc;
-   if (timed) SPH_TRY(hipEventRecord(ev[2], st));
+   if (timed && phase_event(ctx, 2) == 2) SPH_TRY(hipEventRecord(ev[2], st));
    if ((rc = launch_density(ctx))) return rc;
    if (timed) SPH_TRY(hipEventRecord(ev[3], st));
-   // (computePressure is a no-op in the reference, src/sph.cpp:253-263)
-   if (timed) SPH_TRY(hipEventRecord(ev[4], st));
    if ((rc = launch_accel(ctx))) return rc;
    if (timed) SPH_TRY(hipEventRecord(ev[5], st));
    if ((rc = launch_integrate(ctx))) return rc;
@@ -776,7 +785,7 @@ int sph_hip_get_timings(sph_hip_context* ctx, float ms[6])
    }
    hipEvent_t* ev = ctx->ev + 7 * ((ctx->ev_steps - 1) % EV_RING);
    SPH_TRY(hipEventSynchronize(ev[6]));
-   for (int k = 0; k < 6; k++) SPH_TRY(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
+   for (int k = 0; k < 6; k++) SPH_TRY(hipEventElapsedTime(&ms[k], ev[phase_event(ctx, k)], ev[phase_event(ctx, k + 1)]));
    return SPH_HIP_OK;
 }
 
@@ -799,7 +808,7 @@ int sph_hip_get_phase_totals(sph_hip_context* ctx, double ms[6], int32_t* steps)
       SPH_TRY(hipEventSynchronize(ev[6]));
       for (int k = 0; k < 6; k++) {
          float t = 0.0f;
-         SPH_TRY(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+         SPH_TRY(hipEventElapsedTime(&t, ev[phase_event(ctx, k)], ev[phase_event(ctx, k + 1)]));
          ms[k] += (double)t;
       }
    }
