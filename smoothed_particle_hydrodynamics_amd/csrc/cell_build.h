@@ -187,9 +187,10 @@ __global__ void __launch_bounds__(256)
 k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
           const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
           uint32_t* __restrict__ perm, int cells_per_plane, int ncells, int own_lo, int own_hi,
-          int sum_lo, int sum_hi)
+          int sum_lo, int sum_hi, int32_t* __restrict__ tile_stats)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (tile_stats && i < TSTAT_COUNT) tile_stats[i] = 0;  // k_tile_desc accumulates into them
    const int n_in = meta[META_N_IN];
    if (i < n_in) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
    if (i == 0) {

@@ -26,7 +26,18 @@
 #include "full_kernels.h"
 
 #define TILE_THREADS 256
-#define TILE_CAP 3008   // candidate positions per workgroup tile (3 x 11.9 KiB; 3 workgroups per CU)
+// The tile lives in dynamic LDS: its capacity (candidate positions per workgroup) is a launch
+// parameter, chosen by the host from the tile sizes the previous steps needed, because the
+// workgroups a CU can hold (and with them the latency hiding of both passes) is set by the LDS
+// a workgroup asks for: 12 B (density) / 16 B (acceleration) per tile entry.
+#define TILE_PAD 32                      // slots past the capacity that aligned 8-slot reads may touch
+#define TILE_CAP_MAX (4096 - TILE_PAD)   // tile indices are 12-bit in the list entries
+#define TILE_BATCH 8                     // 16-byte loads a thread keeps in flight while filling the tile
+#define DENSITY_TILE_BYTES 12
+#define ACCEL_TILE_BYTES 16
+// launch bounds = the most workgroups per CU the register budget should allow
+#define DENSITY_BLOCKS 6
+#define ACCEL_BLOCKS 5
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
 // NLIST_WORDS rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
 // reads/writes 256 contiguous bytes).  Only rows in use are ever touched.
@@ -54,23 +65,24 @@ __device__ __forceinline__ f32x4 lds_read4(const float* base, int i)
 }
 
 static_assert(DENSITY_UNROLL % 2 == 0 && ACCEL_UNROLL % 2 == 0 && NLIST_CAP % 2 == 0, "entries travel in pairs");
-static_assert(TILE_CAP + 32 <= (1 << QUEUE_TBITS), "tile index must fit the queue entry");
-#define TILE_ROUNDS ((TILE_CAP + TILE_THREADS - 1) / TILE_THREADS)
+static_assert(TILE_CAP_MAX + TILE_PAD <= (1 << QUEUE_TBITS), "tile index must fit the list entry");
 
 // Per-workgroup tile layout, computed by k_tile_desc before the sums run.
 struct TileDesc {
    int D[9];      // tile index = sorted index + D[k] inside segment k
    int B[9];      // first tile index of segment k (B[0] = 0)
-   int total;     // tile entries; > TILE_CAP => the workgroup takes the untiled kernel
+   int total;     // tile entries; > the launch's tile capacity => the workgroup runs untiled
    int pad;
 };
 
+// SoA tile of the density pass inside the dynamic LDS block: three arrays of cap + TILE_PAD floats
 struct TileLds {
-   __attribute__((aligned(16))) float x[TILE_CAP + 32];
-   __attribute__((aligned(16))) float y[TILE_CAP + 32];
-   __attribute__((aligned(16))) float z[TILE_CAP + 32];
-   TileDesc desc;
+   float* x;
+   float* y;
+   float* z;
 };
+
+extern __shared__ __attribute__((aligned(16))) float tile_lds_dynamic[];
 
 // One thread per workgroup-to-be: the 9 row segments (cells c_first-1 .. c_last+1 of every
 // (dz,dy) row, as linear cell-id ranges) of the 256 particles starting at tile*256, as ranges
@@ -78,93 +90,115 @@ struct TileLds {
 __global__ void __launch_bounds__(256)
 k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
             const int32_t* __restrict__ meta, int range, CellGrid g, int ntiles,
-            TileDesc* __restrict__ desc)
+            TileDesc* __restrict__ desc, TileCaps caps, int32_t* __restrict__ stats,
+            uint32_t* __restrict__ giveup_density, uint32_t* __restrict__ giveup_accel)
 {
    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-   if (tile >= ntiles) return;
    const int begin = meta[range], end = meta[range + 1];
    const int p0 = begin + tile * TILE_THREADS;
-   if (p0 >= end) return;
-   const int plast = min(p0 + TILE_THREADS - 1, end - 1);
-   const float4 a = posm[p0], b = posm[plast];
-   int cx, cy, cz;
-   const int c_first = (int)cell_of(g, a.x, a.y, a.z, cx, cy, cz);
-   const int c_last = (int)cell_of(g, b.x, b.y, b.z, cx, cy, cz);
-   TileDesc d;
-   int G[9], len[9];
+   int most = -1;   // -1: no workgroup here
+   if (tile < ntiles && p0 < end) {
+      const int plast = min(p0 + TILE_THREADS - 1, end - 1);
+      const float4 a = posm[p0], b = posm[plast];
+      int cx, cy, cz;
+      const int c_first = (int)cell_of(g, a.x, a.y, a.z, cx, cy, cz);
+      const int c_last = (int)cell_of(g, b.x, b.y, b.z, cx, cy, cz);
+      TileDesc d;
+      int G[9], len[9];
 #pragma unroll
-   for (int k = 0; k < 9; k++) {
-      const int off = ((k / 3 - 1) * g.ny + (k % 3 - 1)) * g.nx;
-      int lo = c_first + off - 1, hi = c_last + off + 1;
-      lo = lo < 0 ? 0 : lo;
-      hi = hi > g.ncells - 1 ? g.ncells - 1 : hi;
-      G[k] = 0;
-      len[k] = 0;
-      if (hi >= lo) {
-         G[k] = (int)cell_start[lo];
-         len[k] = (int)cell_start[hi + 1] - G[k];
-      }
-   }
-   // Segments come in ascending sorted position.  Where consecutive ones overlap or touch (short
-   // rows: a 256-particle span then covers several rows, and the dy = -1, 0, +1 segments of a
-   // plane are nearly the same range) they share tile storage: same index shift D, and only the
-   // part past the previous segment's end is new.  B[k] = first tile index of segment k's new
-   // part, so "tile index t in [B[k], B[k+1])  <->  sorted index t - D[k]" holds for the loader.
-   int run = 0, chain_end = -1, chain_d = 0;
-#pragma unroll
-   for (int k = 0; k < 9; k++) {
-      d.B[k] = run;
-      if (len[k] == 0) {          // nothing to load, no lane range refers to it
-         d.D[k] = run - G[k];
-      } else if (G[k] <= chain_end) {
-         const int seg_end = G[k] + len[k];
-         d.D[k] = chain_d;
-         if (seg_end > chain_end) {
-            run += seg_end - chain_end;
-            chain_end = seg_end;
+      for (int k = 0; k < 9; k++) {
+         const int off = ((k / 3 - 1) * g.ny + (k % 3 - 1)) * g.nx;
+         int lo = c_first + off - 1, hi = c_last + off + 1;
+         lo = lo < 0 ? 0 : lo;
+         hi = hi > g.ncells - 1 ? g.ncells - 1 : hi;
+         G[k] = 0;
+         len[k] = 0;
+         if (hi >= lo) {
+            G[k] = (int)cell_start[lo];
+            len[k] = (int)cell_start[hi + 1] - G[k];
          }
-      } else {
-         d.D[k] = chain_d = run - G[k];
-         run += len[k];
-         chain_end = G[k] + len[k];
       }
+      // Segments come in ascending sorted position.  Where consecutive ones overlap or touch (short
+      // rows: a 256-particle span then covers several rows, and the dy = -1, 0, +1 segments of a
+      // plane are nearly the same range) they share tile storage: same index shift D, and only the
+      // part past the previous segment's end is new.  B[k] = first tile index of segment k's new
+      // part, so "tile index t in [B[k], B[k+1])  <->  sorted index t - D[k]" holds for the loader.
+      int run = 0, chain_end = -1, chain_d = 0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+         d.B[k] = run;
+         if (len[k] == 0) {          // nothing to load, no lane range refers to it
+            d.D[k] = run - G[k];
+         } else if (G[k] <= chain_end) {
+            const int seg_end = G[k] + len[k];
+            d.D[k] = chain_d;
+            if (seg_end > chain_end) {
+               run += seg_end - chain_end;
+               chain_end = seg_end;
+            }
+         } else {
+            d.D[k] = chain_d = run - G[k];
+            run += len[k];
+            chain_end = G[k] + len[k];
+         }
+      }
+      d.total = run;
+      d.pad = 0;
+      desc[tile] = d;
+      most = run;
    }
-   d.total = run;
-   d.pad = 0;
-   desc[tile] = d;
+   // Statistics for the host's next choice of capacity (k_scatter zeroed them): one atomic per
+   // wave and counter, and only for counters that moved.
+   const bool lead = (threadIdx.x & (SPH_WAVE - 1)) == 0;
+   const int counted = __popcll(__ballot(most >= 0));
+   if (lead && counted) atomicAdd(&stats[TSTAT_BLOCKS], counted);
+#pragma unroll
+   for (int c = 0; c < TILE_CANDS; c++) {
+      const int over = __popcll(__ballot(c < caps.n_cand && most > caps.cand[c]));
+      if (lead && over) atomicAdd(&stats[TSTAT_OVER + c], over);
+   }
+   int wave_most = most;
+#pragma unroll
+   for (int o = SPH_WAVE / 2; o > 0; o >>= 1) wave_most = max(wave_most, __shfl_xor(wave_most, o));
+   if (lead && wave_most > 0) atomicMax(&stats[TSTAT_MAX], wave_most);
+   // Workgroups whose tile does not fit this step's capacities: listed, so that the first
+   // workgroups of the two passes compute them (untiled) before anything else - their long
+   // latency then overlaps the rest of the launch instead of trailing it.
+   if (most > caps.cap_density) giveup_density[atomicAdd(&stats[TSTAT_GIVEUP_DENSITY], 1)] = (uint32_t)tile;
+   if (most > caps.cap_density || most > caps.cap_accel)
+      giveup_accel[atomicAdd(&stats[TSTAT_GIVEUP_ACCEL], 1)] = (uint32_t)tile;
 }
 
-template <class Lds>
-__device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, Lds& L)
+__device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, TileDesc& sd)
 {
    const int tid = threadIdx.x;
    if (tid < (int)(sizeof(TileDesc) / sizeof(int)))
-      reinterpret_cast<int*>(&L.desc)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
+      reinterpret_cast<int*>(&sd)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
    __syncthreads();
 }
 
-// Copies the candidate positions of the workgroup's tile into LDS: every thread issues all of
-// its (at most TILE_ROUNDS) 16-byte loads before the first LDS store.
-__device__ __forceinline__ void tile_load(const float4* __restrict__ posm,
-                                          const TileDesc* __restrict__ desc, TileLds& L)
+// Copies the candidate positions of the workgroup's tile into LDS, TILE_BATCH 16-byte loads per
+// thread in flight before the first LDS store of a batch.  The descriptor is already in LDS.
+__device__ __forceinline__ void tile_load(const float4* __restrict__ posm, const TileDesc& sd,
+                                          const TileLds& L)
 {
    const int tid = threadIdx.x;
-   const int total = L.desc.total;  // descriptor already in LDS (tile_desc_load)
+   const int total = sd.total;
+   int B[9], D[9];
+#pragma unroll
+   for (int k = 0; k < 9; k++) {
+      B[k] = sd.B[k];
+      D[k] = sd.D[k];
+   }
 #if defined(SPH_ABLATE) && (SPH_ABLATE == 3 || SPH_ABLATE == 5)
-   if (false) {
+   for (int base = 0; base < 0; base += TILE_BATCH * TILE_THREADS) {
 #else
-   if (total <= TILE_CAP) {
+   for (int base = 0; base < total; base += TILE_BATCH * TILE_THREADS) {
 #endif
-      int B[9], D[9];
+      float4 buf[TILE_BATCH];
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
-         B[k] = L.desc.B[k];
-         D[k] = L.desc.D[k];
-      }
-      float4 buf[TILE_ROUNDS];
-#pragma unroll
-      for (int r = 0; r < TILE_ROUNDS; r++) {
-         const int idx = tid + r * TILE_THREADS;
+      for (int r = 0; r < TILE_BATCH; r++) {
+         const int idx = base + tid + r * TILE_THREADS;
          if (idx < total) {
             int d = D[0];
 #pragma unroll
@@ -173,8 +207,8 @@ __device__ __forceinline__ void tile_load(const float4* __restrict__ posm,
          }
       }
 #pragma unroll
-      for (int r = 0; r < TILE_ROUNDS; r++) {
-         const int idx = tid + r * TILE_THREADS;
+      for (int r = 0; r < TILE_BATCH; r++) {
+         const int idx = base + tid + r * TILE_THREADS;
          if (idx < total) {
             L.x[idx] = buf[r].x;
             L.y[idx] = buf[r].y;
@@ -229,20 +263,49 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
 // list doubles as the input of the acceleration pass.  A workgroup in which some particle has
 // more than NLIST_CAP neighbours gives up (flag) and runs the untiled code inline instead.
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
-__global__ void __launch_bounds__(TILE_THREADS, 4)
+__global__ void __launch_bounds__(TILE_THREADS, DENSITY_BLOCKS)
 k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
                      const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
                      CellGrid g, PairConsts k, float* __restrict__ rho_out,
                      float4* __restrict__ velB_out, float* __restrict__ auxc_out,
                      int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
-                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow)
+                     uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
+                     int tile_cap, const int32_t* __restrict__ tile_stats,
+                     const uint32_t* __restrict__ giveup, int* __restrict__ tile_feedback)
 {
-   __shared__ __attribute__((aligned(16))) TileLds L;
+   __shared__ TileDesc sd;
    __shared__ int list_overflow;
+   TileLds L;
+   L.x = tile_lds_dynamic;
+   L.y = L.x + (tile_cap + TILE_PAD);
+   L.z = L.y + (tile_cap + TILE_PAD);
+   // this step's tile statistics, for the host's next choice of capacity (plain stores to pinned
+   // host memory; read there without synchronisation, only a hint)
+   if (blockIdx.x == 0 && threadIdx.x < TSTAT_COUNT) tile_feedback[threadIdx.x] = tile_stats[threadIdx.x];
 
    const int begin = meta[META_SUM_BEGIN];
    const int end = meta[META_SUM_END];
    const int tid = threadIdx.x;
+   // The untiled code runs in two situations, written as one call site inside a loop so that the
+   // (large) inlined body exists once: (1) the first workgroups of the launch start with the
+   // workgroups whose tile does not fit (give-up list), (2) a workgroup one of whose neighbour
+   // lists overflowed comes back here for its own particles.
+   int untiled_p = -1;
+   bool untiled_pending = (int)blockIdx.x < tile_stats[TSTAT_GIVEUP_DENSITY];  // uniform
+   if (untiled_pending) {
+      const int gp = begin + (int)giveup[blockIdx.x] * TILE_THREADS + tid;
+      if (gp < end) untiled_p = gp;
+   }
+   bool own_done = false;
+   for (;;) {
+   if (untiled_pending) {
+      if (untiled_p >= 0)
+         density_untiled<UNIT_SCALE>(untiled_p, posm, cell_start, velp, g, k, rho_out, velB_out,
+                                     auxc_out, ncount);
+      untiled_pending = false;
+   }
+   if (own_done) return;
+   own_done = true;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
    if (p0 >= end) return;
    const int p = p0 + tid;
@@ -253,13 +316,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    // out before the tile's loads, so that both are in flight together.
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
    if (live) pi = posm[p];
-   tile_desc_load(desc, L);
-   if (L.desc.total > TILE_CAP) {
-      // tile does not fit: this workgroup computes its particles the untiled way, right here
-      // (a separate fallback launch costs ~55 us per step even when it has nothing to do)
+   tile_desc_load(desc, sd);
+   if (sd.total > tile_cap) {
+      // tile does not fit: on the give-up lists, computed by the first workgroups of both passes
       if (tid == 0) nlist_overflow[blockIdx.x] = 1u;
-      if (live) density_untiled<UNIT_SCALE>(p, posm, cell_start, velp, g, k, rho_out, velB_out,
-                                            auxc_out, ncount);
       return;
    }
    RowRanges r;
@@ -272,8 +332,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       row_ranges(g, cell_start, cx, cy, cz, r);
 #endif
    }
-   tile_load(posm, desc, L);
-   const int self_t = p + L.desc.D[4];
+   tile_load(posm, sd, L);
+   const int self_t = p + sd.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
    // uniform base of the workgroup's list block; lanes address it with 32-bit offsets
    uint32_t* list_block = nlist + (size_t)blockIdx.x * (NLIST_WORDS * TILE_THREADS);
@@ -283,7 +343,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    uint32_t hold = 0;  // an even-numbered entry waiting for its partner
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
-      const int D = L.desc.D[kk];
+      const int D = sd.D[kk];
       const uint32_t kbits = (uint32_t)kk << QUEUE_TBITS;
       const int ts = (int)r.s[kk] + D;
       const int te = (int)r.e[kk] + D;
@@ -335,11 +395,13 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    if (count > NLIST_CAP) list_overflow = 1;
    __syncthreads();
    const int give_up = list_overflow;
-   if (tid == 0) nlist_overflow[blockIdx.x] = (uint32_t)give_up;
-   if (give_up) {  // a list did not fit: redo the workgroup the untiled way
-      if (live) density_untiled<UNIT_SCALE>(p, posm, cell_start, velp, g, k, rho_out, velB_out,
-                                            auxc_out, ncount);
-      return;
+   if (tid == 0) nlist_overflow[blockIdx.x] = give_up ? 2u : 0u;
+   if (give_up) {
+      // a list did not fit: the workgroup computes its particles the untiled way, right here (a
+      // separate fallback launch costs ~55 us per step even when it has nothing to do)
+      untiled_p = live ? p : -1;
+      untiled_pending = true;
+      continue;
    }
 
    // SUM: one pass over the list, in canonical order
@@ -360,7 +422,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          if (j0 + u < count) {
             const int t = (int)(entry[u] & QUEUE_TMASK);
             float mj = pi.w;
-            if (!UNIFORM_MASS) mj = posm[t - L.desc.D[entry[u] >> QUEUE_TBITS]].w;
+            if (!UNIFORM_MASS) mj = posm[t - sd.D[entry[u] >> QUEUE_TBITS]].w;
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
             float d = sqrtf(d2);
@@ -378,6 +440,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       auxc_out[p] = bc.y;                              // ... and what it stages in its tile
       ncount[p] = count;
    }
+   return;
+   }  // for (;;)
 }
 
 // ---- acceleration pass: list-driven, no TEST ------------------------------------------------------
@@ -385,10 +449,9 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // tile indices).  The pass is bound by the per-neighbour gathers, so the tile also holds the
 // neighbour's viscosity coefficient C_j next to x/y/z and the only global gather left per
 // neighbour is one 16-byte {vx, vy, vz, B_j}.
+// The tile (dynamic LDS) is an array of {x, y, z, C}: this pass never scans it, it only looks
+// single neighbours up, so one ds_read_b128 per neighbour beats four scattered ds_read_b32.
 struct AccelLds {
-   // array of {x, y, z, C}: this pass never scans the tile, it only looks single neighbours up,
-   // so one ds_read_b128 per neighbour beats four scattered ds_read_b32
-   float4 xyzc[TILE_CAP + 32];
    TileDesc desc;
    int hist[2 * SPH_WAVE];         // neighbour-count histogram / its exclusive scan (NLIST_CAP+1 used)
    uint16_t perm[TILE_THREADS];    // lane -> list column, ascending neighbour count
@@ -396,37 +459,58 @@ struct AccelLds {
 static_assert(NLIST_CAP + 1 <= 2 * SPH_WAVE, "count histogram is scanned by one wave, two entries per lane");
 
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
-__global__ void __launch_bounds__(TILE_THREADS, 3)
+__global__ void __launch_bounds__(TILE_THREADS, ACCEL_BLOCKS)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
                    const float* __restrict__ rho, const float* __restrict__ auxc,
                    const int32_t* __restrict__ ncount, const uint32_t* __restrict__ cell_start,
                    const int32_t* __restrict__ meta, CellGrid g, PairConsts k,
                    float4* __restrict__ acc, const TileDesc* __restrict__ desc,
-                   const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow)
+                   const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow,
+                   int tile_cap, const int32_t* __restrict__ tile_stats,
+                   const uint32_t* __restrict__ giveup)
 {
-   __shared__ __attribute__((aligned(16))) AccelLds L;
+   __shared__ AccelLds L;
+   float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
 
    const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
    const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
    const int tid = threadIdx.x;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
-   // nothing to do for workgroups past the range or made of ghosts only
-   if (p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) return;
-   if (nlist_overflow[blockIdx.x]) {
-      // the density pass gave up on this workgroup's tile or lists: untiled path, inline
-      const int pp = p0 + tid;
-      if (pp < end && pp >= ob && pp < oe)
-         accel_untiled<UNIT_SCALE>(pp, posm, velB, rho, auxc, cell_start, g, k, acc);
-      return;
+   // nothing of its own to do for workgroups past the range or made of ghosts only
+   const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe);
+   // 1: tile did not fit the density pass (on the give-up list), 2: a neighbour list overflowed
+   const uint32_t gave_up = own ? nlist_overflow[blockIdx.x] : 1u;
+   // Untiled work, one call site: [0] the first workgroups of the launch start with the
+   // workgroups whose tile does not fit (give-up list), so that their long latency overlaps the
+   // rest of the launch; [1] a workgroup whose lists overflowed computes its own particles.
+   {
+      int untiled_p[2] = {-1, -1};
+      const bool listed = (int)blockIdx.x < tile_stats[TSTAT_GIVEUP_ACCEL];
+      if (listed) {
+         const int gp = begin + (int)giveup[blockIdx.x] * TILE_THREADS + tid;
+         if (gp < end && gp >= ob && gp < oe) untiled_p[0] = gp;
+      }
+      if (gave_up == 2u) {
+         const int pp = p0 + tid;
+         if (pp < end && pp >= ob && pp < oe) untiled_p[1] = pp;
+      }
+#pragma unroll 1
+      for (int u = 0; u < 2; u++) {
+         if (u == 0 ? listed : gave_up == 2u) {  // uniform
+            const int q = u == 0 ? untiled_p[0] : untiled_p[1];
+            if (q >= 0) accel_untiled<UNIT_SCALE>(q, posm, velB, rho, auxc, cell_start, g, k, acc);
+         }
+      }
    }
+   if (gave_up) return;
    int my_cnt = 0;  // requested before the tile: the lane permutation below needs it
    {
       const int pp = p0 + tid;
       if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
    }
-   tile_desc_load(desc, L);
+   tile_desc_load(desc, L.desc);
    const int total = L.desc.total;
-   if (total > TILE_CAP) return;
+   if (total > tile_cap) return;  // does not fit this pass's wider entries: on the give-up list
    {
       int B[9], D[9];
 #pragma unroll
@@ -434,23 +518,25 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          B[kk] = L.desc.B[kk];
          D[kk] = L.desc.D[kk];
       }
-      float4 buf[TILE_ROUNDS];
-      float cbuf[TILE_ROUNDS];
+      for (int base = 0; base < total; base += TILE_BATCH * TILE_THREADS) {
+         float4 buf[TILE_BATCH];
+         float cbuf[TILE_BATCH];
 #pragma unroll
-      for (int r = 0; r < TILE_ROUNDS; r++) {
-         const int idx = tid + r * TILE_THREADS;
-         if (idx < total) {
-            int d = D[0];
+         for (int r = 0; r < TILE_BATCH; r++) {
+            const int idx = base + tid + r * TILE_THREADS;
+            if (idx < total) {
+               int d = D[0];
 #pragma unroll
-            for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
-            buf[r] = posm[idx - d];
-            cbuf[r] = auxc[idx - d];
+               for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
+               buf[r] = posm[idx - d];
+               cbuf[r] = auxc[idx - d];
+            }
          }
-      }
 #pragma unroll
-      for (int r = 0; r < TILE_ROUNDS; r++) {
-         const int idx = tid + r * TILE_THREADS;
-         if (idx < total) L.xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
+         for (int r = 0; r < TILE_BATCH; r++) {
+            const int idx = base + tid + r * TILE_THREADS;
+            if (idx < total) xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
+         }
       }
    }
    __syncthreads();
@@ -529,7 +615,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          if (j0 + u < cnt) {
-            const float4 pj = L.xyzc[entry[u] & QUEUE_TMASK];
+            const float4 pj = xyzc[entry[u] & QUEUE_TMASK];
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             float d = sqrtf(d2);

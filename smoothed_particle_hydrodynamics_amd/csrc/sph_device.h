@@ -43,6 +43,25 @@ enum {
    META_ERRORS = 6,    // bit 0: entry outside slab+halo, bit 1: message overflow, bit 2: capacity
    META_COUNT = 8
 };
+
+// Per-step statistics of the LDS tiles (k_tile_desc), fed back to the host's choice of tile
+// capacity: how many workgroups would not fit each candidate capacity.
+#define TILE_CANDS 8
+enum {
+   TSTAT_OVER = 0,          // [TILE_CANDS] workgroups whose tile exceeds candidate i
+   TSTAT_BLOCKS = 8,        // workgroups counted
+   TSTAT_MAX = 9,           // largest tile
+   TSTAT_GIVEUP_DENSITY = 10, // entries of the give-up lists of the current step
+   TSTAT_GIVEUP_ACCEL = 11,
+   TSTAT_COUNT = 16
+};
+struct TileCaps {
+   int cand[TILE_CANDS];    // ascending candidate capacities (the occupancy levels of both kernels)
+   int n_cand;
+   int cap_density;         // capacities the current step's launches use
+   int cap_accel;
+};
+
 #define SPH_DEAD_ID 0xffffffffu
 
 // Constants of the per-pair arithmetic, by value in kernarg (scalar registers).
@@ -108,6 +127,17 @@ struct sph_hip_context {
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
+   // LDS tile capacity of the two tiled kernels: chosen per launch among the largest tiles that
+   // still allow B workgroups per CU (levels, ascending), from the tile size recent steps needed
+   // (tile_feedback: pinned host word the density kernel stores into; 0 = nothing known yet)
+   int* tile_feedback = nullptr;   // TSTAT_COUNT ints, pinned host memory
+   int32_t* tile_stats = nullptr;  // TSTAT_* of the current step (device)
+   uint32_t* giveup_density = nullptr; // workgroups whose tile exceeds the density capacity
+   uint32_t* giveup_accel = nullptr;   // ... or the acceleration capacity
+   int tile_cap_forced = 0;        // SPH_HIP_TILE_CAP: fixed capacity for both kernels (tests)
+   int density_levels[TILE_CANDS] = {0}, n_density_levels = 0;
+   int accel_levels[TILE_CANDS] = {0}, n_accel_levels = 0;
+   TileCaps caps = {};             // candidate capacities + the two chosen for the current step
 
    // REF-mode lists
    int32_t* vox = nullptr; // 3 ints per particle

@@ -76,7 +76,7 @@ void free_all(sph_hip_context* ctx)
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
                    ctx->scan_part, ctx->rho, ctx->velB, ctx->auxc, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
                    ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta, ctx->nlist,
-                   ctx->nlist_overflow};
+                   ctx->nlist_overflow, ctx->tile_stats, ctx->giveup_density, ctx->giveup_accel};
    for (void* q : ptrs)
       if (q) (void)hipFree(q);
    if (ctx->ev) {
@@ -84,6 +84,7 @@ void free_all(sph_hip_context* ctx)
          if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
       delete[] ctx->ev;
    }
+   if (ctx->tile_feedback) (void)hipHostFree(ctx->tile_feedback);
    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 }
 
@@ -130,7 +131,7 @@ int launch_cell_build(sph_hip_context* ctx)
    const int sum_hi = own_hi + 1 > g.nz ? g.nz : own_hi + 1;
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
                       ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
-                      sum_lo, sum_hi);
+                      sum_lo, sum_hi, ctx->tile_stats);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
                          ctx->cell_start, ctx->meta, ctx->order);
@@ -160,14 +161,113 @@ int launch_find_neighbors(sph_hip_context* ctx)
    return SPH_HIP_OK;
 }
 
+// ---- LDS tile capacity ---------------------------------------------------------------------
+// For every workgroups-per-CU count B a tiled kernel can reach, the largest tile (multiple of
+// 32 entries) that still lets B workgroups share a CU.  The runtime's occupancy calculator
+// knows the kernel's registers and static LDS; 2 KiB of slack per workgroup cover the
+// allocation granularity of the hardware, which it rounds more finely than the device does
+// (measured: a size it rated 3/CU ran at 2/CU).
+template <class Kernel>
+int tile_levels(Kernel kernel, int bytes_per_entry, int* levels)
+{
+   auto blocks_at = [&](int cap) {
+      int nb = 0;
+      const size_t bytes = (size_t)(cap + TILE_PAD) * bytes_per_entry + 2048;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, TILE_THREADS, bytes) != hipSuccess) {
+         (void)hipGetLastError();
+         return 0;
+      }
+      return nb;
+   };
+   // dynamic LDS beyond 64 KiB would need an opt-in attribute; the 12-bit tile index stops earlier
+   int cap_max = TILE_CAP_MAX;
+   while (cap_max > 256 && (size_t)(cap_max + TILE_PAD) * bytes_per_entry > 60 * 1024) cap_max -= 32;
+   const int cap_min = 1024 - TILE_PAD;
+   int n = 0, prev = 0;
+   for (int want = blocks_at(cap_min); want >= 2 && n < TILE_CANDS / 2; want--) {
+      int lo = cap_min, hi = cap_max;            // largest cap with blocks_at(cap) >= want
+      while (lo < hi) {
+         const int mid = lo + ((hi - lo) / 32 + 1) / 2 * 32;
+         if (blocks_at(mid) >= want) lo = mid;
+         else hi = mid - 32;
+      }
+      if (lo > prev) levels[n++] = prev = lo;
+      if (lo >= cap_max) break;
+   }
+   if (n == 0) levels[n++] = 3008;               // no answer from the runtime: a size that fits
+   if (getenv("SPH_HIP_DEBUG")) {
+      fprintf(stderr, "sph_hip: tile capacity levels (%d B/entry):", bytes_per_entry);
+      for (int l = 0; l < n; l++) fprintf(stderr, " %d (%d/CU)", levels[l], blocks_at(levels[l]));
+      fprintf(stderr, "\n");
+   }
+   return n;
+}
+
+// Smallest level that all but ~0.2 % of the workgroups of the latest reported step fit in (the
+// rest are computed untiled, by the first workgroups of the launch: same results).  An untiled
+// workgroup takes ~100 us from start to end however little else there is to do, so launches too
+// short to hide that tolerate none.  Nothing reported yet: the level next to 3008 entries.
+int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, int n)
+{
+   const int blocks = fb[TSTAT_BLOCKS];
+   if (blocks <= 0) {
+      for (int l = 0; l < n; l++)
+         if (levels[l] >= 3008) return levels[l];
+      return levels[n - 1];
+   }
+   const int tolerated = blocks >= 8192 ? blocks / 512 : 0;
+   for (int l = 0; l < n; l++)
+      for (int c = 0; c < ctx->caps.n_cand; c++)
+         if (ctx->caps.cand[c] == levels[l] && fb[TSTAT_OVER + c] <= tolerated) return levels[l];
+   return levels[n - 1];
+}
+
+// Capacities for the step about to be launched (before its k_tile_desc, which lists the
+// workgroups that will not fit them).
+void pick_tile_caps(sph_hip_context* ctx)
+{
+   TileCaps& caps = ctx->caps;
+   if (caps.n_cand == 0) {
+      ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true>, DENSITY_TILE_BYTES,
+                                          ctx->density_levels);
+      ctx->n_accel_levels = tile_levels(k_full_accel_lists<true, true>, ACCEL_TILE_BYTES,
+                                        ctx->accel_levels);
+      // candidates = ascending union of both kernels' levels
+      int nd = 0, na = 0;
+      while ((nd < ctx->n_density_levels || na < ctx->n_accel_levels) && caps.n_cand < TILE_CANDS) {
+         const int d = nd < ctx->n_density_levels ? ctx->density_levels[nd] : INT32_MAX;
+         const int a = na < ctx->n_accel_levels ? ctx->accel_levels[na] : INT32_MAX;
+         const int v = d < a ? d : a;
+         if (d == v) nd++;
+         if (a == v) na++;
+         caps.cand[caps.n_cand++] = v;
+      }
+   }
+   if (ctx->tile_cap_forced > 0) {
+      caps.cap_density = caps.cap_accel = ctx->tile_cap_forced;
+      return;
+   }
+   int fb[TSTAT_COUNT];
+   for (int i = 0; i < TSTAT_COUNT; i++) fb[i] = ((volatile int*)ctx->tile_feedback)[i];
+   caps.cap_density = pick_level(ctx, fb, ctx->density_levels, ctx->n_density_levels);
+   caps.cap_accel = pick_level(ctx, fb, ctx->accel_levels, ctx->n_accel_levels);
+   static int debug_left = getenv("SPH_HIP_DEBUG") ? 6 : 0;
+   if (debug_left > 0 && debug_left--)
+      fprintf(stderr, "sph_hip: %d workgroups, largest tile %d -> capacities %d / %d\n",
+              fb[TSTAT_BLOCKS], fb[TSTAT_MAX], caps.cap_density, caps.cap_accel);
+}
+
 // tiled kernels of the two sums, specialised on (unit simulation scale, uniform mass)
 void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
 {
+   const int cap = ctx->caps.cap_density;
+   const size_t lds = (size_t)(cap + TILE_PAD) * DENSITY_TILE_BYTES;
 #define SPH_GO(U, M)                                                                             \
-   hipLaunchKernelGGL((k_full_density_tiled<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,         \
+   hipLaunchKernelGGL((k_full_density_tiled<U, M>), dim3(blocks), dim3(TILE_THREADS), lds,       \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
                       ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
-                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
+                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
+                      ctx->giveup_density, ctx->tile_feedback)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -177,16 +277,32 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
 
 void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
 {
+   const int cap = ctx->caps.cap_accel;
+   const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
 #define SPH_GO(U, M)                                                                             \
-   hipLaunchKernelGGL((k_full_accel_lists<U, M>), dim3(blocks), dim3(TILE_THREADS), 0,           \
+   hipLaunchKernelGGL((k_full_accel_lists<U, M>), dim3(blocks), dim3(TILE_THREADS), lds,         \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
                       ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
-                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow)
+                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
+                      ctx->giveup_accel)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
    else SPH_GO(false, false);
 #undef SPH_GO
+}
+
+// Chooses the step's tile capacities, then lays out the LDS tile of every 256-particle
+// workgroup of the density range (+ statistics and give-up lists for those capacities)
+void launch_tile_desc(sph_hip_context* ctx)
+{
+   static_assert(sizeof(TileDesc) == 20 * sizeof(int), "TileDesc is 20 ints");
+   pick_tile_caps(ctx);
+   const int blocks = div_up(ctx->n, TILE_THREADS);
+   hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
+                      ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
+                      ctx->grid, blocks, ctx->tile_desc, ctx->caps, ctx->tile_stats,
+                      ctx->giveup_density, ctx->giveup_accel);
 }
 
 int launch_density(sph_hip_context* ctx)
@@ -201,10 +317,7 @@ int launch_density(sph_hip_context* ctx)
    } else {
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
-         static_assert(sizeof(TileDesc) == 20 * sizeof(int), "TileDesc is 20 ints");
-         hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
-                            ctx->grid, blocks, ctx->tile_desc);
+         launch_tile_desc(ctx);
          launch_density_tiled(ctx, unit, blocks, k);  // give-up workgroups fall back inline
       } else if (unit) {                               // SPH_HIP_UNTILED=1: untiled everywhere
          hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
@@ -453,6 +566,16 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS));
       CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
       if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
+      CREATE_TRY(hipHostMalloc((void**)&ctx->tile_feedback, TSTAT_COUNT * sizeof(int), hipHostMallocDefault));
+      memset(ctx->tile_feedback, 0, TSTAT_COUNT * sizeof(int));
+      CREATE_TRY(dev_alloc(&ctx->tile_stats, TSTAT_COUNT));
+      CREATE_TRY(hipMemsetAsync(ctx->tile_stats, 0, TSTAT_COUNT * sizeof(int32_t), ctx->stream));
+      CREATE_TRY(dev_alloc(&ctx->giveup_density, (size_t)div_up(capacity, TILE_THREADS) + 1));
+      CREATE_TRY(dev_alloc(&ctx->giveup_accel, (size_t)div_up(capacity, TILE_THREADS) + 1));
+      if (const char* v = getenv("SPH_HIP_TILE_CAP")) {
+         const int c = atoi(v);
+         if (c > 0) ctx->tile_cap_forced = c < 256 ? 256 : (c > 3008 ? 3008 : c / 32 * 32);  // 48 KiB at most
+      }
    } else {
       CREATE_TRY(dev_alloc(&ctx->order, cap));
       CREATE_TRY(dev_alloc(&ctx->vox, cap * 3));
@@ -562,6 +685,24 @@ static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const floa
       hipLaunchKernelGGL(k_import, dim3(div_up(n, 256)), dim3(256), 0, st, spos, svel, smass,
                          ids ? sids : (const uint32_t*)nullptr, n, ctx->posm[0], ctx->velp[0]);
       SPH_TRY(hipGetLastError());
+   }
+   if (ctx->tile_feedback) {
+      // Tile capacity of the first steps: nothing has run yet to report what the scene needs,
+      // and the host may enqueue many steps before the first one finishes, so sort the upload
+      // once here (the first step's cell build then finds it already in canonical order) and
+      // read the largest tile back.
+      memset(ctx->tile_feedback, 0, TSTAT_COUNT * sizeof(int));
+      if (n > 0 && ctx->use_tiled) {
+         int rc = launch_cell_build(ctx);
+         if (rc) return rc;
+         launch_tile_desc(ctx);
+         SPH_TRY(hipGetLastError());
+         int stats[TSTAT_COUNT];
+         SPH_TRY(hipMemcpyAsync(stats, ctx->tile_stats, sizeof(stats), hipMemcpyDeviceToHost,
+                                ctx->stream));
+         SPH_TRY(hipStreamSynchronize(ctx->stream));
+         memcpy(ctx->tile_feedback, stats, sizeof(stats));
+      }
    }
    SPH_TRY(hipStreamSynchronize(ctx->stream));
    return SPH_HIP_OK;

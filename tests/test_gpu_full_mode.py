@@ -170,3 +170,33 @@ def test_full_tiled_equals_untiled(oracle, hiplib, monkeypatch):
                         ("mPosition", "mVelocity", "mDensity", "mAcceleration", "mNeighborCount")])
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cap", ["512", "1504", "2048", "3008"])
+def test_full_any_tile_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
+    """The LDS tile capacity is a per-launch performance choice (occupancy levels picked from the
+    tile sizes recent steps needed).  SPH_HIP_TILE_CAP pins it: at 512 every workgroup is on the
+    give-up lists and computed untiled by the first workgroups of the launch, at 1504 a mix, at
+    3008 none - the results must not depend on it."""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    monkeypatch.setenv("SPH_HIP_TILE_CAP", cap)
+    p, pos, vel, mass = scenes.dam_break(60000)
+    run_case(oracle, p, pos, vel, mass, steps=2)
+
+
+def test_full_capacity_follows_the_scene(oracle, hiplib):
+    """Same context, two uploads of very different density: the capacity chosen from the first
+    scene's statistics must not leak wrong results into the second (it is only a hint)."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(40000)
+    pd, posd, veld, massd = scenes.dam_break(40000, fill=(0.05, 0.4, 0.5))   # 7.5x denser, same h
+    op = to_oracle_params(p)
+    with S.SPH(mass.size, p, mode=S.MODE_FULL) as sph:
+        for q, v in ((pos, vel), (posd, veld), (pos, vel)):
+            sph.setParticles(q, v, mass)
+            oq, ov = q.copy(), v.copy()
+            for s in range(2):
+                sph.step()
+                ref = oracle.step(op, oq, ov, mass, mode="full")
+            check_state(sph.getParticles(), ref)
