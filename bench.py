@@ -32,7 +32,12 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=4 * 1024 * 1024,
-                    help="total particles (default: BASELINE config C3, 4M)")
+                    help="particles of the 1-GPU workload (default: BASELINE config C3, 4M)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = --particles per GPU in a box N times as long in z "
+                         "(one unit box per slab); strong = --particles in total, unit box")
+    ap.add_argument("--no-other-scaling", action="store_true",
+                    help="N > 1: skip the shorter measurement of the other scaling mode")
     ap.add_argument("--cpu-sample", type=int, default=131072,
                     help="particles in the CPU-baseline sample (0 disables)")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -104,19 +109,30 @@ def run_single(args, S, scenes, torch, local_rank):
     return p, dt, totals, covered, n, nb_mean, "1 GPU"
 
 
-def run_slabs(args, S, scenes, torch, rank, world, local_rank):
-    """N > 1: one z-slab of the cell grid per GPU, neighbour exchange over RCCL (xGMI)."""
+def run_slabs(args, S, scenes, torch, rank, world, local_rank, scaling, steps, warmup):
+    """N > 1: one z-slab of the cell grid per GPU, neighbour exchange over RCCL (xGMI).
+
+    weak: the column is `world` unit boxes long in z and holds world x --particles (every slab
+    is the 1-GPU workload plus its halos); strong: the 1-GPU workload itself is cut in `world`
+    slabs.  Every rank derives the same cuts from the z coordinates alone and generates only
+    the particles it owns (counter-based PRNG: any subset of the scene on any rank)."""
     import torch.distributed as dist
     from smoothed_particle_hydrodynamics_amd import slab as SL
-    n = args.particles
-    p, pos, vel, mass = scenes.dam_break(n)       # every rank derives the same scene and cuts
-    z = pos.reshape(-1, 3)[:, 2]
+    n = args.particles * world if scaling == "weak" else args.particles
+    box = (1.0, 1.0, float(world)) if scaling == "weak" else (1.0, 1.0, 1.0)
+    p, hi = scenes.dam_break_params(n, box)
+    z = scenes.box_fill_axis(n, (0.0, 0.0, 0.0), hi, 2)
+    planes = SL.plane_of(p, z)
     cuts = SL.plan_cuts(p, z, world)
-    hist = np.bincount(SL.plane_of(p, z), minlength=p.full_cells_z)
+    hist = np.bincount(planes, minlength=p.full_cells_z)
     cap, msg = SL.slab_capacities(hist, cuts, rank, slack=1.5)
+    mine = np.nonzero((planes >= cuts[rank]) & (planes < cuts[rank + 1]))[0]
+    del z, planes
     slab = SL.HipSlab(p, cuts[rank], cuts[rank + 1], cap, msg, device=local_rank,
                       has_left=rank > 0, has_right=rank + 1 < world)
-    slab.upload(*SL.split_scene(p, cuts, rank, pos, vel, mass), all_masses_equal=True)
+    slab.upload(mine.astype(np.uint32), scenes.box_fill_subset(mine, (0.0, 0.0, 0.0), hi),
+                np.zeros(3 * mine.size, np.float32), np.ones(mine.size, np.float32),
+                all_masses_equal=True)
     # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P)
     host = os.environ.get("SPH_SLAB_TRANSPORT") == "host"
     transport = (SL.HostStagedTransport if host else SL.DistTransport)(rank, world)
@@ -127,12 +143,12 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank):
         torch.cuda.synchronize()
         dist.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         stepper.step()
     fence()
     slab.reset_timings()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         stepper.step()
     fence()
     dt_local = time.perf_counter() - t0
@@ -151,7 +167,10 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank):
     totals, covered = slab.phase_totals()
     d = slab.download()
     nb_mean = float(d["ncount"].mean())
-    return p, dt, totals, covered, st["owned"], nb_mean, "z-slab x%d, RCCL halo" % world
+    slab.close()
+    return {"params": p, "dt": dt, "totals": totals, "covered": covered, "n": n,
+            "n_rank": st["owned"], "neighbors_mean": nb_mean, "steps": steps, "box": box,
+            "parallelism": "z-slab x%d, RCCL halo" % world}
 
 
 def main():
@@ -186,11 +205,23 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         dist.barrier()
-        p, dt, totals, covered, n_rank, nb_mean, par = run_slabs(args, S, scenes, torch, rank,
-                                                                 world, local_rank)
+        r = run_slabs(args, S, scenes, torch, rank, world, local_rank, args.scaling, args.steps,
+                      args.warmup)
+        p, dt, totals, covered = r["params"], r["dt"], r["totals"], r["covered"]
+        n, n_rank, nb_mean, par, box = r["n"], r["n_rank"], r["neighbors_mean"], r["parallelism"], r["box"]
+        other = None
+        if not args.no_other_scaling:
+            # the other scaling mode, shorter, reported beside the headline (never as `value`)
+            mode = "strong" if args.scaling == "weak" else "weak"
+            o = run_slabs(args, S, scenes, torch, rank, world, local_rank, mode,
+                          max(5, args.steps // 2), min(args.warmup, 2))
+            other = {"scaling": mode, "particles": o["n"], "box": list(o["box"]),
+                     "value": o["n"] * o["steps"] / o["dt"] / 1e6, "unit": "Mparticle-steps/s",
+                     "steps": o["steps"], "ms_per_step": o["dt"] / o["steps"] * 1e3}
     else:
         p, dt, totals, covered, n_rank, nb_mean, par = run_single(args, S, scenes, torch,
                                                                   local_rank)
+        box, other = (1.0, 1.0, 1.0), None
 
     if rank == 0:
         # phases: 0 cell build, 1 findNeighbors (fused), 2 density, 3 pressure (empty),
@@ -206,17 +237,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "dam-break %d particles%s in the unit box, fp32, FULL neighbour "
+                "workload": "dam-break %d particles%s in a %gx%gx%g box, fp32, FULL neighbour "
                             "mode, cell grid rebuilt every step" % (
                                 n, {262144: " (BASELINE configs[1], C2)",
                                     4194304: " (BASELINE configs[2], C3)",
-                                    16777216: " (BASELINE configs[3], C4)"}.get(n, "")),
+                                    16777216: " (BASELINE configs[3], C4)"}.get(n, "")
+                                if world == 1 or args.scaling == "strong" else
+                                " = %d x the 1-GPU workload (BASELINE configs[2], C3), one unit "
+                                "box per slab along z" % world, box[0], box[1], box[2]),
                 "particles": n,
+                "particles_per_gpu": n // world,
                 "h": float(p.h),
                 "grid": [p.full_cells_x, p.full_cells_y, p.full_cells_z],
                 "neighbors_mean": nb_mean,
@@ -242,6 +277,8 @@ def main():
                         "64 B/particle compulsory-traffic figure of SURVEY.md 8(d)",
             },
         }
+        if other is not None:
+            line["other_scaling"] = other
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
         print(json.dumps(line))

@@ -44,6 +44,33 @@ def dam_break_h(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0):
     return (3.0 * neighbors / (4.0 * math.pi * number_density)) ** (1.0 / 3.0)
 
 
+def box_fill_axis(n, lo, hi, axis, seed=42):
+    """Coordinate `axis` of box_fill(n, lo, hi, seed)'s points, without the other two."""
+    idx = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(axis)
+    u = uniform01(seed, idx)
+    lo = np.float32(lo[axis])
+    return (lo + u * (np.float32(hi[axis]) - lo)).astype(np.float32)
+
+
+def box_fill_subset(ids, lo, hi, seed=42):
+    """Rows `ids` of box_fill(n, lo, hi, seed) (any n > max(ids)), interleaved xyz."""
+    ids = np.asarray(ids, np.uint64)
+    idx = (ids[:, None] * np.uint64(3) + np.arange(3, dtype=np.uint64)[None, :]).reshape(-1)
+    u = uniform01(seed, idx).reshape(-1, 3)
+    lo = np.asarray(lo, np.float32)
+    ext = np.asarray(hi, np.float32) - lo
+    return np.ascontiguousarray((lo + u * ext).astype(np.float32).reshape(-1))
+
+
+def dam_break_params(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0):
+    """(params, column extent) of dam_break(n, box, fill, neighbors) without any particle."""
+    h = np.float32(dam_break_h(n, box, fill, neighbors))
+    cells = [max(1, int(math.ceil(b / (2.0 * float(h))))) for b in box]
+    p = default_params(float(h), cells)
+    p.central_mass = 0.0
+    return p, [box[c] * fill[c] for c in range(3)]
+
+
 def dam_break(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0, seed=42):
     """Dam-break column modelled on the reference's commented-out init (src/sph.cpp:328-345):
     uniform random points in x<0.1*Lx, y<0.75*Ly, z<Lz, at rest, unit masses.
@@ -52,11 +79,7 @@ def dam_break(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0, see
     central point mass is switched off (it is the astrophysical part of the reference's
     default scene, not of a dam-break); everything else keeps the reference's defaults.
     """
-    h = np.float32(dam_break_h(n, box, fill, neighbors))
-    cells = [max(1, int(math.ceil(b / (2.0 * float(h))))) for b in box]
-    p = default_params(float(h), cells)
-    p.central_mass = 0.0
-    hi = [box[c] * fill[c] for c in range(3)]
+    p, hi = dam_break_params(n, box, fill, neighbors)
     pos = box_fill(n, (0.0, 0.0, 0.0), hi, seed)
     vel = np.zeros(3 * n, np.float32)
     mass = np.ones(n, np.float32)
