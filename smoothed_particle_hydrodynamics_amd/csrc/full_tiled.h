@@ -286,26 +286,14 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const int begin = meta[META_SUM_BEGIN];
    const int end = meta[META_SUM_END];
    const int tid = threadIdx.x;
-   // The untiled code runs in two situations, written as one call site inside a loop so that the
-   // (large) inlined body exists once: (1) the first workgroups of the launch start with the
-   // workgroups whose tile does not fit (give-up list), (2) a workgroup one of whose neighbour
-   // lists overflowed comes back here for its own particles.
-   int untiled_p = -1;
-   bool untiled_pending = (int)blockIdx.x < tile_stats[TSTAT_GIVEUP_DENSITY];  // uniform
-   if (untiled_pending) {
+   // the first workgroups of the launch start with the workgroups whose tile does not fit
+   // (give-up list), untiled: their long latency then overlaps the rest of the launch
+   if ((int)blockIdx.x < tile_stats[TSTAT_GIVEUP_DENSITY]) {
       const int gp = begin + (int)giveup[blockIdx.x] * TILE_THREADS + tid;
-      if (gp < end) untiled_p = gp;
+      if (gp < end)
+         density_untiled<UNIT_SCALE>(gp, posm, cell_start, velp, g, k, rho_out, velB_out, auxc_out,
+                                     ncount);
    }
-   bool own_done = false;
-   for (;;) {
-   if (untiled_pending) {
-      if (untiled_p >= 0)
-         density_untiled<UNIT_SCALE>(untiled_p, posm, cell_start, velp, g, k, rho_out, velB_out,
-                                     auxc_out, ncount);
-      untiled_pending = false;
-   }
-   if (own_done) return;
-   own_done = true;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
    if (p0 >= end) return;
    const int p = p0 + tid;
@@ -396,17 +384,42 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    __syncthreads();
    const int give_up = list_overflow;
    if (tid == 0) nlist_overflow[blockIdx.x] = give_up ? 2u : 0u;
+   float density = 0.0f;
    if (give_up) {
-      // a list did not fit: the workgroup computes its particles the untiled way, right here (a
-      // separate fallback launch costs ~55 us per step even when it has nothing to do)
-      untiled_p = live ? p : -1;
-      untiled_pending = true;
-      continue;
+      // Some particle of the workgroup has more than NLIST_CAP neighbours (a scene several times
+      // denser than the lists are sized for): no lists.  Every lane walks its candidate ranges
+      // in the tile one by one - canonical order, small code; the acceleration pass computes the
+      // workgroup untiled.  (A separate fallback launch would cost every step ~55 us.)
+      count = 0;
+      RowRanges rr;   // looked up again rather than kept alive through TEST in every workgroup
+#pragma unroll
+      for (int kk = 0; kk < 9; kk++) rr.s[kk] = rr.e[kk] = 0;
+      if (live) {
+         int cx, cy, cz;
+         cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
+         row_ranges(g, cell_start, cx, cy, cz, rr);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 9; kk++) {
+         const int D = sd.D[kk];
+         const int te = (int)rr.e[kk] + D;
+         for (int t = (int)rr.s[kk] + D; t < te; t++) {
+            float dx, dy, dz;
+            const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+            if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
+               float mj = pi.w;
+               if (!UNIFORM_MASS) mj = posm[t - D].w;
+               float d = sqrtf(d2);
+               if (!UNIT_SCALE) d *= k.sim_scale;
+               density_accumulate(k, mj, d, density);
+               count++;
+            }
+         }
+      }
    }
 
    // SUM: one pass over the list, in canonical order
-   float density = 0.0f;
-   for (int j0 = 0; __any(j0 < count); j0 += DENSITY_UNROLL) {
+   for (int j0 = 0; !give_up && __any(j0 < count); j0 += DENSITY_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
       uint32_t entry[DENSITY_UNROLL];
       const int lastw = count > 0 ? (count - 1) >> 1 : 0;
@@ -440,8 +453,6 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       auxc_out[p] = bc.y;                              // ... and what it stages in its tile
       ncount[p] = count;
    }
-   return;
-   }  // for (;;)
 }
 
 // ---- acceleration pass: list-driven, no TEST ------------------------------------------------------
