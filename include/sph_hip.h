@@ -164,6 +164,15 @@ int sph_hip_get_timings(sph_hip_context* ctx, float ms[6]);
  * steps the sums cover.  Measured with HIP events on the context's own stream. */
 int sph_hip_get_phase_totals(sph_hip_context* ctx, double ms[6], int32_t* steps);
 int sph_hip_reset_timings(sph_hip_context* ctx);
+/* What sph_hip_step() times (an event record is a barrier packet: ~10 us each on the stream).
+ * SPH_HIP_TIMING_PHASES (default): every phase boundary, as SPH::updateElapsed wants.
+ * SPH_HIP_TIMING_SUMS: only the density + acceleration pair, as one interval - reported in
+ * slot 2 (density) of the two calls above, the other slots 0.  SPH_HIP_TIMING_OFF: nothing
+ * (sph_hip_get_timings fails, the totals cover 0 steps).  Resets the collected timings. */
+#define SPH_HIP_TIMING_OFF 0
+#define SPH_HIP_TIMING_SUMS 1
+#define SPH_HIP_TIMING_PHASES 2
+int sph_hip_set_timing(sph_hip_context* ctx, int level);
 
 /* mKineticEnergyTotal / mPotentialEnergyTotal of the last integrate
  * (reference src/sph.cpp:1001-1013).  Summed in double in a fixed tree order; the

@@ -127,6 +127,7 @@ struct sph_hip_context {
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
+   int timing_level = 2;           // SPH_HIP_TIMING_*: which events sph_hip_step() records
    // LDS tile capacity of the two tiled kernels: chosen per launch among the largest tiles that
    // still allow B workgroups per CU (levels, ascending), from the tile size recent steps needed
    // (tile_feedback: pinned host word the density kernel stores into; 0 = nothing known yet)

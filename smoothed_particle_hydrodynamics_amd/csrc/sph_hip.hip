@@ -397,18 +397,35 @@ int step_impl(sph_hip_context* ctx, bool timed)
    int rc;
    hipStream_t st = ctx->stream;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
-   if (timed) SPH_TRY(hipEventRecord(ev[0], st));
+   const int level = timed ? ctx->timing_level : SPH_HIP_TIMING_OFF;
+   const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
+   if (phases) SPH_TRY(hipEventRecord(ev[0], st));
    if ((rc = launch_cell_build(ctx))) return rc;
-   if (timed) SPH_TRY(hipEventRecord(ev[1], st));
+   if (phases || sums) SPH_TRY(hipEventRecord(ev[1], st));
    if ((rc = launch_find_neighbors(ctx))) return rc;
-   if (timed && phase_event(ctx, 2) == 2) SPH_TRY(hipEventRecord(ev[2], st));
+   if (phases && phase_event(ctx, 2) == 2) SPH_TRY(hipEventRecord(ev[2], st));
    if ((rc = launch_density(ctx))) return rc;
-   if (timed) SPH_TRY(hipEventRecord(ev[3], st));
+   if (phases) SPH_TRY(hipEventRecord(ev[3], st));
    if ((rc = launch_accel(ctx))) return rc;
-   if (timed) SPH_TRY(hipEventRecord(ev[5], st));
+   if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
    if ((rc = launch_integrate(ctx))) return rc;
-   if (timed) SPH_TRY(hipEventRecord(ev[6], st));
-   if (timed) ctx->ev_steps++;
+   if (phases) SPH_TRY(hipEventRecord(ev[6], st));
+   if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;
+   return SPH_HIP_OK;
+}
+
+// the six phase times of the step in ring slot `ev` (see sph_hip_set_timing)
+int read_phases(sph_hip_context* ctx, hipEvent_t* ev, float ms[6])
+{
+   for (int k = 0; k < 6; k++) ms[k] = 0.0f;
+   if (ctx->timing_level == SPH_HIP_TIMING_SUMS) {
+      SPH_TRY(hipEventSynchronize(ev[5]));
+      SPH_TRY(hipEventElapsedTime(&ms[2], ev[1], ev[5]));
+      return SPH_HIP_OK;
+   }
+   SPH_TRY(hipEventSynchronize(ev[6]));
+   for (int k = 0; k < 6; k++)
+      SPH_TRY(hipEventElapsedTime(&ms[k], ev[phase_event(ctx, k)], ev[phase_event(ctx, k + 1)]));
    return SPH_HIP_OK;
 }
 
@@ -924,9 +941,20 @@ int sph_hip_get_timings(sph_hip_context* ctx, float ms[6])
       ctx->err = "sph_hip_get_timings: no sph_hip_step() has run since the last upload/reset";
       return SPH_HIP_ERR_INVALID;
    }
-   hipEvent_t* ev = ctx->ev + 7 * ((ctx->ev_steps - 1) % EV_RING);
-   SPH_TRY(hipEventSynchronize(ev[6]));
-   for (int k = 0; k < 6; k++) SPH_TRY(hipEventElapsedTime(&ms[k], ev[phase_event(ctx, k)], ev[phase_event(ctx, k + 1)]));
+   return read_phases(ctx, ctx->ev + 7 * ((ctx->ev_steps - 1) % EV_RING), ms);
+}
+
+int sph_hip_set_timing(sph_hip_context* ctx, int level)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (level < SPH_HIP_TIMING_OFF || level > SPH_HIP_TIMING_PHASES) {
+      ctx->err = "sph_hip_set_timing: level must be SPH_HIP_TIMING_OFF, _SUMS or _PHASES";
+      return SPH_HIP_ERR_INVALID;
+   }
+   SPH_TRY(hipStreamSynchronize(ctx->stream));  // events of the old level are not read any more
+   ctx->timing_level = level;
+   ctx->ev_steps = 0;
    return SPH_HIP_OK;
 }
 
@@ -945,13 +973,9 @@ int sph_hip_get_phase_totals(sph_hip_context* ctx, double ms[6], int32_t* steps)
    const long long have = ctx->ev_steps < EV_RING ? ctx->ev_steps : EV_RING;
    for (int k = 0; k < 6; k++) ms[k] = 0.0;
    for (long long s = ctx->ev_steps - have; s < ctx->ev_steps; s++) {
-      hipEvent_t* ev = ctx->ev + 7 * (s % EV_RING);
-      SPH_TRY(hipEventSynchronize(ev[6]));
-      for (int k = 0; k < 6; k++) {
-         float t = 0.0f;
-         SPH_TRY(hipEventElapsedTime(&t, ev[phase_event(ctx, k)], ev[phase_event(ctx, k + 1)]));
-         ms[k] += (double)t;
-      }
+      float one[6];
+      if ((rc = read_phases(ctx, ctx->ev + 7 * (s % EV_RING), one))) return rc;
+      for (int k = 0; k < 6; k++) ms[k] += (double)one[k];
    }
    *steps = (int32_t)have;
    return SPH_HIP_OK;

@@ -6,6 +6,8 @@ from .build import library_path
 
 MODE_REF = 0
 MODE_FULL = 1
+# sph_hip_set_timing levels (include/sph_hip.h)
+TIMING_OFF, TIMING_SUMS, TIMING_PHASES = 0, 1, 2
 
 
 class SphHipError(RuntimeError):
@@ -73,6 +75,7 @@ PROTOTYPES = {
     "sph_hip_get_timings": (C.c_int, [_ctx, _P(C.c_float * 6)]),
     "sph_hip_get_phase_totals": (C.c_int, [_ctx, _P(C.c_double * 6), _P(C.c_int32)]),
     "sph_hip_reset_timings": (C.c_int, [_ctx]),
+    "sph_hip_set_timing": (C.c_int, [_ctx, C.c_int]),
     "sph_hip_get_energy": (C.c_int, [_ctx, _P(C.c_float), _P(C.c_float)]),
     "sph_hip_get_neighbor_stats": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "sph_hip_download_voxels": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),

@@ -176,6 +176,9 @@ class HipSlab:
                     "sph_hip_get_phase_totals")
         return list(ms), k.value
 
+    def set_timing(self, level):
+        self._check(self._lib.sph_hip_set_timing(self._ctx, int(level)), "sph_hip_set_timing")
+
     def reset_timings(self):
         self._check(self._lib.sph_hip_reset_timings(self._ctx), "sph_hip_reset_timings")
 

@@ -268,6 +268,11 @@ class SPH:
     def resetTimings(self):
         self._check(self._lib.sph_hip_reset_timings(self._ctx), "sph_hip_reset_timings")
 
+    def setTiming(self, level):
+        """Which intervals step() times: TIMING_PHASES (default, all six), TIMING_SUMS (density +
+        acceleration as one interval, in slot 2), TIMING_OFF.  Resets the collected timings."""
+        self._check(self._lib.sph_hip_set_timing(self._ctx, int(level)), "sph_hip_set_timing")
+
     def phaseTotals(self):
         """(sum of the six phase times in ms over the step() calls since resetTimings(), steps)"""
         ms = (C.c_double * 6)()

@@ -200,3 +200,34 @@ def test_full_capacity_follows_the_scene(oracle, hiplib):
                 sph.step()
                 ref = oracle.step(op, oq, ov, mass, mode="full")
             check_state(sph.getParticles(), ref)
+
+
+def test_timing_levels(hiplib):
+    """sph_hip_set_timing: PHASES fills all work slots, SUMS only slot 2 (density+acceleration as
+    one interval, close to the two PHASES slots together), OFF collects nothing; results of the
+    step are the same at every level."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(200000)
+    acc = []
+    with S.SPH(mass.size, p) as sph:
+        for level in (S.TIMING_PHASES, S.TIMING_SUMS, S.TIMING_OFF):
+            sph.setParticles(pos, vel, mass)
+            sph.setTiming(level)
+            for _ in range(4):
+                sph.step()
+            sph.synchronize()
+            t, k = sph.phaseTotals()
+            if level == S.TIMING_PHASES:
+                assert k == 4 and t[0] > 0 and t[2] > 0 and t[4] > 0 and t[5] > 0 and t[1] == 0 and t[3] == 0
+                pair = t[2] + t[4]
+            elif level == S.TIMING_SUMS:
+                assert k == 4 and t[2] > 0 and t[0] == t[1] == t[3] == t[4] == t[5] == 0
+                assert 0.5 * pair < t[2] < 1.5 * pair
+                assert sph.elapsed()[2] > 0
+            else:
+                assert k == 0
+                with pytest.raises(S.SphHipError):
+                    sph.elapsed()
+            acc.append(sph.getParticles().mAcceleration.copy())
+    assert np.array_equal(acc[0], acc[1]) and np.array_equal(acc[0], acc[2])
