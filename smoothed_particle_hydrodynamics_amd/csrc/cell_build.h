@@ -190,7 +190,8 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
           int sum_lo, int sum_hi, int32_t* __restrict__ tile_stats)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (tile_stats && i < TSTAT_COUNT) tile_stats[i] = 0;  // k_tile_desc accumulates into them
+   // tile statistics of the step: the descriptor pass accumulates into them
+   if (tile_stats && i < TSTAT_COUNT && i != TSTAT_BLOCKS) tile_stats[i] = 0;
    const int n_in = meta[META_N_IN];
    if (i < n_in) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
    if (i == 0) {
@@ -202,6 +203,8 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
       meta[META_OWN_END] = (int)cell_start[own_hi * cells_per_plane];
       meta[META_SUM_BEGIN] = (int)cell_start[sum_lo * cells_per_plane];
       meta[META_SUM_END] = (int)cell_start[sum_hi * cells_per_plane];
+      if (tile_stats)   // 256-particle workgroups of the density range
+         tile_stats[TSTAT_BLOCKS] = (meta[META_SUM_END] - meta[META_SUM_BEGIN] + 255) / 256;
    }
 }
 
@@ -222,13 +225,12 @@ k_rank_order(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key
 }
 
 // ---- 4b. FULL: gather the state into cell-sorted order, ascending persistent id in a cell ----
-__global__ void __launch_bounds__(256)
-k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
-              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, int trash,
-              const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
-              float4* __restrict__ posm_out, float4* __restrict__ velp_out)
+__device__ __forceinline__ void
+rank_gather(int p, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
+            const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, int trash,
+            const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
+            float4* __restrict__ posm_out, float4* __restrict__ velp_out)
 {
-   const int p = blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= meta[META_N_IN]) return;
    const uint32_t i = perm[p];
    const uint32_t c = key[i];
@@ -249,4 +251,14 @@ k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ ke
    }
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;
+}
+
+__global__ void __launch_bounds__(256)
+k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
+              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, int trash,
+              const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
+              float4* __restrict__ posm_out, float4* __restrict__ velp_out)
+{
+   rank_gather(blockIdx.x * blockDim.x + threadIdx.x, perm, key, cell_start, meta, trash, posm_in,
+               velp_in, posm_out, velp_out);
 }

@@ -86,23 +86,23 @@ extern __shared__ __attribute__((aligned(16))) float tile_lds_dynamic[];
 
 // One thread per workgroup-to-be: the 9 row segments (cells c_first-1 .. c_last+1 of every
 // (dz,dy) row, as linear cell-id ranges) of the 256 particles starting at tile*256, as ranges
-// of the sorted arrays plus their placement in the LDS tile.
-__global__ void __launch_bounds__(256)
-k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
-            const int32_t* __restrict__ meta, int range, CellGrid g, int ntiles,
-            TileDesc* __restrict__ desc, TileCaps caps, int32_t* __restrict__ stats,
-            uint32_t* __restrict__ giveup_density, uint32_t* __restrict__ giveup_accel)
+// of the sorted arrays plus their placement in the LDS tile.  Needs only the counting sort's
+// key/perm/cell_start (not the sorted state), so it shares a launch with the gather below.
+__device__ __forceinline__ void
+tile_desc(int tile, int ntiles, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
+          const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
+          TileDesc* __restrict__ desc, const TileCaps& caps, int32_t* __restrict__ stats,
+          uint32_t* __restrict__ giveup_density, uint32_t* __restrict__ giveup_accel)
 {
-   const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-   const int begin = meta[range], end = meta[range + 1];
+   const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
    const int p0 = begin + tile * TILE_THREADS;
    int most = -1;   // -1: no workgroup here
    if (tile < ntiles && p0 < end) {
       const int plast = min(p0 + TILE_THREADS - 1, end - 1);
-      const float4 a = posm[p0], b = posm[plast];
-      int cx, cy, cz;
-      const int c_first = (int)cell_of(g, a.x, a.y, a.z, cx, cy, cz);
-      const int c_last = (int)cell_of(g, b.x, b.y, b.z, cx, cy, cz);
+      // position p of the sorted order lies in the cell of perm[p] (ordered by id inside the
+      // cell only after the gather, but the cell is the same)
+      const int c_first = (int)key[perm[p0]];
+      const int c_last = (int)key[perm[plast]];
       TileDesc d;
       int G[9], len[9];
 #pragma unroll
@@ -118,11 +118,12 @@ k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_s
             len[k] = (int)cell_start[hi + 1] - G[k];
          }
       }
-      // Segments come in ascending sorted position.  Where consecutive ones overlap or touch (short
-      // rows: a 256-particle span then covers several rows, and the dy = -1, 0, +1 segments of a
-      // plane are nearly the same range) they share tile storage: same index shift D, and only the
-      // part past the previous segment's end is new.  B[k] = first tile index of segment k's new
-      // part, so "tile index t in [B[k], B[k+1])  <->  sorted index t - D[k]" holds for the loader.
+      // Segments come in ascending sorted position.  Where consecutive ones overlap or touch
+      // (short rows: a 256-particle span then covers several rows, and the dy = -1, 0, +1
+      // segments of a plane are nearly the same range) they share tile storage: same index
+      // shift D, and only the part past the previous segment's end is new.  B[k] = first tile
+      // index of segment k's new part, so "tile index t in [B[k], B[k+1])  <->  sorted index
+      // t - D[k]" holds for the loader.
       int run = 0, chain_end = -1, chain_d = 0;
 #pragma unroll
       for (int k = 0; k < 9; k++) {
@@ -148,10 +149,8 @@ k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_s
       most = run;
    }
    // Statistics for the host's next choice of capacity (k_scatter zeroed them): one atomic per
-   // wave and counter, and only for counters that moved.
+   // wave and counter, and only for counters that move.
    const bool lead = (threadIdx.x & (SPH_WAVE - 1)) == 0;
-   const int counted = __popcll(__ballot(most >= 0));
-   if (lead && counted) atomicAdd(&stats[TSTAT_BLOCKS], counted);
 #pragma unroll
    for (int c = 0; c < TILE_CANDS; c++) {
       const int over = __popcll(__ballot(c < caps.n_cand && most > caps.cand[c]));
@@ -160,13 +159,34 @@ k_tile_desc(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_s
    int wave_most = most;
 #pragma unroll
    for (int o = SPH_WAVE / 2; o > 0; o >>= 1) wave_most = max(wave_most, __shfl_xor(wave_most, o));
-   if (lead && wave_most > 0) atomicMax(&stats[TSTAT_MAX], wave_most);
+   if (lead && wave_most > stats[TSTAT_MAX]) atomicMax(&stats[TSTAT_MAX], wave_most);
    // Workgroups whose tile does not fit this step's capacities: listed, so that the first
    // workgroups of the two passes compute them (untiled) before anything else - their long
    // latency then overlaps the rest of the launch instead of trailing it.
    if (most > caps.cap_density) giveup_density[atomicAdd(&stats[TSTAT_GIVEUP_DENSITY], 1)] = (uint32_t)tile;
    if (most > caps.cap_density || most > caps.cap_accel)
       giveup_accel[atomicAdd(&stats[TSTAT_GIVEUP_ACCEL], 1)] = (uint32_t)tile;
+}
+
+// Last launch of the FULL-mode cell build: the first `desc_blocks` workgroups lay out the tiles
+// (a short chain of dependent loads, hidden behind the gather), the others gather the state
+// into cell-sorted order.
+__global__ void __launch_bounds__(256)
+k_rank_gather_tile_desc(int desc_blocks, int ntiles, const uint32_t* __restrict__ perm,
+                        const uint32_t* __restrict__ key, const uint32_t* __restrict__ cell_start,
+                        const int32_t* __restrict__ meta, CellGrid g,
+                        const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
+                        float4* __restrict__ posm_out, float4* __restrict__ velp_out,
+                        TileDesc* __restrict__ desc, TileCaps caps, int32_t* __restrict__ stats,
+                        uint32_t* __restrict__ giveup_density, uint32_t* __restrict__ giveup_accel)
+{
+   if ((int)blockIdx.x < desc_blocks) {
+      tile_desc(blockIdx.x * blockDim.x + threadIdx.x, ntiles, perm, key, cell_start, meta, g, desc,
+                caps, stats, giveup_density, giveup_accel);
+      return;
+   }
+   rank_gather((blockIdx.x - desc_blocks) * blockDim.x + threadIdx.x, perm, key, cell_start, meta,
+               g.ncells, posm_in, velp_in, posm_out, velp_out);
 }
 
 __device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, TileDesc& sd)

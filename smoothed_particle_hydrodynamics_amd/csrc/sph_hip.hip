@@ -101,66 +101,6 @@ int check_ctx(sph_hip_context* ctx)
 
 // ---- phase launches (no event recording, no host sync) ---------------------------------------
 
-int launch_cell_build(sph_hip_context* ctx)
-{
-   const int n = ctx->n;  // host upper bound of entries; the exact count is meta[META_N_IN]
-   if (n == 0) return SPH_HIP_OK;
-   const int blocks = div_up(n, 256);
-   const CellGrid g = ctx->grid;
-   hipStream_t st = ctx->stream;
-   const int cur = ctx->cur;
-   if (ctx->mode == SPH_HIP_MODE_REF)
-      hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
-                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
-                         ctx->vox);
-   else
-      hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
-                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
-                         (int32_t*)nullptr);
-   // the scan covers the real cells plus the trash cell, so cell_start[ncells] = live entries
-   const int tiles = ctx->scan_tiles;
-   const int ncells_scan = g.ncells + 1;
-   hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
-                      ncells_scan, ctx->scan_part);
-   hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(SCAN_THREADS), 0, st, ctx->scan_part, tiles);
-   hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
-                      ncells_scan, ctx->scan_part, ctx->cell_start);
-   // sorted ranges: owned planes [lo, hi), density planes one wider (clipped to what is held)
-   const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
-   const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
-   const int sum_hi = own_hi + 1 > g.nz ? g.nz : own_hi + 1;
-   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
-                      ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
-                      sum_lo, sum_hi, ctx->tile_stats);
-   if (ctx->mode == SPH_HIP_MODE_REF) {
-      hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
-                         ctx->cell_start, ctx->meta, ctx->order);
-   } else {
-      const int nxt = cur ^ 1;
-      hipLaunchKernelGGL(k_rank_gather, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
-                         ctx->cell_start, ctx->meta, g.ncells, ctx->posm[cur], ctx->velp[cur],
-                         ctx->posm[nxt], ctx->velp[nxt]);
-      ctx->cur = nxt;
-      // The live set is now compacted at the front of the new buffers.  meta[N_IN] still holds
-      // this build's input count: without an exchange nothing was dropped (n_live == n_in), and
-      // with one, sph_hip_slab_unpack resets it to n_live before appending.
-   }
-   SPH_TRY(hipGetLastError());
-   return SPH_HIP_OK;
-}
-
-int launch_find_neighbors(sph_hip_context* ctx)
-{
-   if (ctx->mode != SPH_HIP_MODE_REF || ctx->n == 0) return SPH_HIP_OK;
-   const sph_hip_params& p = ctx->prm;
-   hipLaunchKernelGGL(k_ref_find_neighbors, dim3(div_up(ctx->n, 256)), dim3(256), 0, ctx->stream,
-                      ctx->posm[0], ctx->vox, ctx->cell_start, ctx->order, ctx->n, p.cells_x,
-                      p.cells_y, p.cells_z, p.h, p.htimes2, p.h2, p.sim_scale, p.examine_count,
-                      ctx->nb, ctx->nd, ctx->ncount);
-   SPH_TRY(hipGetLastError());
-   return SPH_HIP_OK;
-}
-
 // ---- LDS tile capacity ---------------------------------------------------------------------
 // For every workgroups-per-CU count B a tiled kernel can reach, the largest tile (multiple of
 // 32 entries) that still lets B workgroups share a CU.  The runtime's occupancy calculator
@@ -257,6 +197,79 @@ void pick_tile_caps(sph_hip_context* ctx)
               fb[TSTAT_BLOCKS], fb[TSTAT_MAX], caps.cap_density, caps.cap_accel);
 }
 
+int launch_cell_build(sph_hip_context* ctx)
+{
+   const int n = ctx->n;  // host upper bound of entries; the exact count is meta[META_N_IN]
+   if (n == 0) return SPH_HIP_OK;
+   const int blocks = div_up(n, 256);
+   const CellGrid g = ctx->grid;
+   hipStream_t st = ctx->stream;
+   const int cur = ctx->cur;
+   if (ctx->mode == SPH_HIP_MODE_REF)
+      hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
+                         ctx->vox);
+   else
+      hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
+                         (int32_t*)nullptr);
+   // the scan covers the real cells plus the trash cell, so cell_start[ncells] = live entries
+   const int tiles = ctx->scan_tiles;
+   const int ncells_scan = g.ncells + 1;
+   hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
+                      ncells_scan, ctx->scan_part);
+   hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(SCAN_THREADS), 0, st, ctx->scan_part, tiles);
+   hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
+                      ncells_scan, ctx->scan_part, ctx->cell_start);
+   // sorted ranges: owned planes [lo, hi), density planes one wider (clipped to what is held)
+   const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
+   const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
+   const int sum_hi = own_hi + 1 > g.nz ? g.nz : own_hi + 1;
+   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
+                      ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
+                      sum_lo, sum_hi, ctx->tile_stats);
+   if (ctx->mode == SPH_HIP_MODE_REF) {
+      hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
+                         ctx->cell_start, ctx->meta, ctx->order);
+   } else {
+      const int nxt = cur ^ 1;
+      if (ctx->use_tiled) {
+         // + the LDS tile layout of every 256-particle workgroup of the density range, with the
+         // statistics and give-up lists for the capacities chosen here for this step's sums
+         static_assert(sizeof(TileDesc) == 20 * sizeof(int), "TileDesc is 20 ints");
+         pick_tile_caps(ctx);
+         const int ntiles = div_up(n, TILE_THREADS), desc_blocks = div_up(ntiles, 256);
+         hipLaunchKernelGGL(k_rank_gather_tile_desc, dim3(desc_blocks + blocks), dim3(256), 0, st,
+                            desc_blocks, ntiles, ctx->perm, ctx->key, ctx->cell_start, ctx->meta,
+                            g, ctx->posm[cur], ctx->velp[cur], ctx->posm[nxt], ctx->velp[nxt],
+                            ctx->tile_desc, ctx->caps, ctx->tile_stats, ctx->giveup_density,
+                            ctx->giveup_accel);
+      } else {
+         hipLaunchKernelGGL(k_rank_gather, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
+                            ctx->cell_start, ctx->meta, g.ncells, ctx->posm[cur], ctx->velp[cur],
+                            ctx->posm[nxt], ctx->velp[nxt]);
+      }
+      ctx->cur = nxt;
+      // The live set is now compacted at the front of the new buffers.  meta[N_IN] still holds
+      // this build's input count: without an exchange nothing was dropped (n_live == n_in), and
+      // with one, sph_hip_slab_unpack resets it to n_live before appending.
+   }
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int launch_find_neighbors(sph_hip_context* ctx)
+{
+   if (ctx->mode != SPH_HIP_MODE_REF || ctx->n == 0) return SPH_HIP_OK;
+   const sph_hip_params& p = ctx->prm;
+   hipLaunchKernelGGL(k_ref_find_neighbors, dim3(div_up(ctx->n, 256)), dim3(256), 0, ctx->stream,
+                      ctx->posm[0], ctx->vox, ctx->cell_start, ctx->order, ctx->n, p.cells_x,
+                      p.cells_y, p.cells_z, p.h, p.htimes2, p.h2, p.sim_scale, p.examine_count,
+                      ctx->nb, ctx->nd, ctx->ncount);
+   SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
 // tiled kernels of the two sums, specialised on (unit simulation scale, uniform mass)
 void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
 {
@@ -292,19 +305,6 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
 #undef SPH_GO
 }
 
-// Chooses the step's tile capacities, then lays out the LDS tile of every 256-particle
-// workgroup of the density range (+ statistics and give-up lists for those capacities)
-void launch_tile_desc(sph_hip_context* ctx)
-{
-   static_assert(sizeof(TileDesc) == 20 * sizeof(int), "TileDesc is 20 ints");
-   pick_tile_caps(ctx);
-   const int blocks = div_up(ctx->n, TILE_THREADS);
-   hipLaunchKernelGGL(k_tile_desc, dim3(div_up(blocks, 256)), dim3(256), 0, ctx->stream,
-                      ctx->posm[ctx->cur], ctx->cell_start, ctx->meta, (int)META_SUM_BEGIN,
-                      ctx->grid, blocks, ctx->tile_desc, ctx->caps, ctx->tile_stats,
-                      ctx->giveup_density, ctx->giveup_accel);
-}
-
 int launch_density(sph_hip_context* ctx)
 {
    const int n = ctx->n;
@@ -317,7 +317,6 @@ int launch_density(sph_hip_context* ctx)
    } else {
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
-         launch_tile_desc(ctx);
          launch_density_tiled(ctx, unit, blocks, k);  // give-up workgroups fall back inline
       } else if (unit) {                               // SPH_HIP_UNTILED=1: untiled everywhere
          hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
@@ -712,8 +711,6 @@ static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const floa
       if (n > 0 && ctx->use_tiled) {
          int rc = launch_cell_build(ctx);
          if (rc) return rc;
-         launch_tile_desc(ctx);
-         SPH_TRY(hipGetLastError());
          int stats[TSTAT_COUNT];
          SPH_TRY(hipMemcpyAsync(stats, ctx->tile_stats, sizeof(stats), hipMemcpyDeviceToHost,
                                 ctx->stream));
