@@ -46,11 +46,15 @@
 // one spare word row swallows overflowing appends
 #define NLIST_WORDS (NLIST_CAP / 2 + 1)
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
+#ifndef DENSITY_UNROLL
 #define DENSITY_UNROLL 6
+#endif
 #ifndef APPEND_POPS
 #define APPEND_POPS 4     // accepted candidates appended per trip of the append loop
 #endif
+#ifndef ACCEL_UNROLL
 #define ACCEL_UNROLL 8
+#endif
 // queue entry: segment id << 12 | tile index (TILE_CAP + 32 <= 4096)
 #define QUEUE_TBITS 12
 #define QUEUE_TMASK 0xfffu
