@@ -267,8 +267,10 @@ def main():
                                     4194304: " (BASELINE configs[2], C3)",
                                     16777216: " (BASELINE configs[3], C4)"}.get(n, "")
                                 if world == 1 or args.scaling == "strong" else
-                                " = %d x the 1-GPU workload (BASELINE configs[2], C3), one unit "
-                                "box per slab along z" % world, box[0], box[1], box[2]),
+                                " = %d x the 1-GPU workload%s, one unit box per slab along z" % (
+                                    world, " (BASELINE configs[2], C3)"
+                                    if args.particles == 4194304 else ""),
+                                box[0], box[1], box[2]),
                 "particles": n,
                 "particles_per_gpu": n // world,
                 "h": float(p.h),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPH_HIP_ABI_VERSION 2
+#define SPH_HIP_ABI_VERSION 3
 
 typedef enum sph_hip_status {
    SPH_HIP_OK = 0,
@@ -213,7 +213,20 @@ int sph_hip_download_neighbor_lists(sph_hip_context* ctx, uint32_t* neighbors, f
  * halo width of (or beyond) a neighbour's border: the receiver treats records inside its own
  * planes as migrants (now owned) and the rest as ghosts; ghosts are dropped and re-sent every
  * step.  All counts stay on the device — none of these calls synchronises with the host.
- * sph_hip_create() is the special case plane_lo = 0, plane_hi = all planes, no neighbours. */
+ * sph_hip_create() is the special case plane_lo = 0, plane_hi = all planes, no neighbours.
+ *
+ * Exchange overlapped with the interior's force computation (after one pack/transport/unpack
+ * round has delivered the first ghosts), per step:
+ *     sph_hip_slab_step_begin   cell build, density, acceleration of the owned planes next to a
+ *                               neighbour (halo + 1 planes), and the two messages: those
+ *                               particles are integrated on the fly, the state is not touched
+ *     <transport>               on ANOTHER stream, after an event recorded behind step_begin
+ *     sph_hip_slab_step_end     acceleration of all other workgroups, integrate - concurrent
+ *                               with the transport
+ *     sph_hip_slab_unpack       after the context's stream has waited for the transport
+ * Same results as the serial sequence.  Last step's ghosts and departed particles are recognised
+ * by the next cell build from their position in the sorted order; error bit 8 reports an
+ * interior particle that crossed more than one cell plane in a step and so missed its message. */
 #define SPH_HIP_SLAB_HALO 2
 
 int sph_hip_create_slab(sph_hip_context** out, const sph_hip_params* params, int capacity,
@@ -233,8 +246,13 @@ int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_devic
                       int capacity_records);
 int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const void* right_device,
                         int capacity_records);
-/* Diagnostics (synchronises): live entries, owned particles, error bits (1: a particle left
- * the slab and its halo in one step, 2: a message overflowed, 4: context capacity exceeded). */
+/* See above.  Message buffers: exactly one per existing neighbour (NULL otherwise). */
+int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right_device,
+                            int capacity_records);
+int sph_hip_slab_step_end(sph_hip_context* ctx);
+/* Diagnostics (synchronises): live entries, owned particles, error bits (1: a received entry
+ * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded,
+ * 8: a particle missed the early exchange). */
 int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors);
 
 /* ---- streams ----------------------------------------------------------------------------- */

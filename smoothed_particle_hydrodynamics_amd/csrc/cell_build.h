@@ -23,7 +23,7 @@
 template <bool WRITE_VOX>
 __global__ void __launch_bounds__(256)
 k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
-             int32_t* __restrict__ meta, CellGrid g, uint32_t* __restrict__ key,
+             int32_t* __restrict__ meta, CellGrid g, SlabZone zone, uint32_t* __restrict__ key,
              uint32_t* __restrict__ slot, uint32_t* __restrict__ cell_count,
              int32_t* __restrict__ vox)
 {
@@ -35,10 +35,32 @@ k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
       const float4 p = posm[i];
       int cx, cy, cz;
       c = cell_of(g, p.x, p.y, p.z, cx, cy, cz);
-      if (__float_as_uint(velp[i].w) == SPH_DEAD_ID)
+      // entries [0, n_live) are the previous sorted order (its owned range still in meta),
+      // entries behind them were received from the neighbours since
+      const bool carried = zone.drop_ghosts && i < meta[META_N_LIVE];
+      const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+      const bool was_owned = i >= ob && i < oe;
+      if (__float_as_uint(velp[i].w) == SPH_DEAD_ID) {
          c = (uint32_t)g.ncells;  // dropped ghost / departed particle
-      else if (c == (uint32_t)g.ncells)
-         atomicOr(&meta[META_ERRORS], 1);  // a live particle outside the slab and its halo
+      } else if (carried && !was_owned) {
+         c = (uint32_t)g.ncells;  // last step's ghost: its owner sends it again every step
+      } else if (c == (uint32_t)g.ncells) {
+         // an owned particle that left the slab and its halo was sent to its new owner (a
+         // migrant); anything else out here is lost: a received entry that does not belong
+         if (!carried) atomicOr(&meta[META_ERRORS], 1);
+      } else if (zone.early && carried) {
+         // The early exchange packed the planes next to the borders before the interior was
+         // integrated.  An interior particle that ended up where it should have been sent
+         // moved more than a cell plane in one step: nobody has it as a ghost - say so.
+         const int lo_end = meta[META_BND_LO_END];
+         const int hi_begin = max(meta[META_BND_HI_BEGIN], lo_end);
+         if (i >= lo_end && i < hi_begin) {
+            const int plane = cell_coord(p.z, g.inv, g.nz_global);
+            if ((zone.have_left && plane < zone.lo + zone.halo) ||
+                (zone.have_right && plane >= zone.hi - zone.halo))
+               atomicOr(&meta[META_ERRORS], 8);
+         }
+      }
       key[i] = c;
       if (WRITE_VOX) {
          vox[3 * i + 0] = cx;
@@ -187,7 +209,7 @@ __global__ void __launch_bounds__(256)
 k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
           const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
           uint32_t* __restrict__ perm, int cells_per_plane, int ncells, int own_lo, int own_hi,
-          int sum_lo, int sum_hi, int32_t* __restrict__ tile_stats)
+          int sum_lo, int sum_hi, int bnd_lo, int bnd_hi, int32_t* __restrict__ tile_stats)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    // tile statistics of the step: the descriptor pass accumulates into them
@@ -203,6 +225,9 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
       meta[META_OWN_END] = (int)cell_start[own_hi * cells_per_plane];
       meta[META_SUM_BEGIN] = (int)cell_start[sum_lo * cells_per_plane];
       meta[META_SUM_END] = (int)cell_start[sum_hi * cells_per_plane];
+      meta[META_BND_LO_END] = (int)cell_start[bnd_lo * cells_per_plane];
+      meta[META_BND_HI_BEGIN] = (int)cell_start[bnd_hi * cells_per_plane];
+      meta[META_MSG_LEFT] = meta[META_MSG_RIGHT] = meta[META_PACK_DONE] = 0;
       if (tile_stats)   // 256-particle workgroups of the density range
          tile_stats[TSTAT_BLOCKS] = (meta[META_SUM_END] - meta[META_SUM_BEGIN] + 255) / 256;
    }

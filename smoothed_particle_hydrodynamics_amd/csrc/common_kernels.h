@@ -45,8 +45,64 @@ __device__ __forceinline__ void handle_boundaries(const PairConsts& k, const flo
 
 // ---- integrate (reference src/sph.cpp:937-1022) -------------------------------------------------
 // "KDK as coded": half kick with the SPH acceleration, drift, then a FULL-dt kick with the
-// point-mass gravity only, evaluated at the new position.  KE/PE contributions are reduced per
-// block in double (the reference's serial fp32 running sum is order dependent).
+// point-mass gravity only, evaluated at the new position (reference src/sph.cpp:937-1022).
+// Updates x (position, mass kept) and v (velocity, id kept); ke/pe = the particle's energy terms.
+template <bool UNIT_SCALE>
+__device__ __forceinline__ void integrate_particle(const PairConsts& k, float4& x, float4& v,
+                                                   const float4 a, double& ke, double& pe)
+{
+   const float dt = k.dt;
+   const float pos_dt = dt * k.sim_scale_inv;
+
+   const float vhx = v.x + (a.x * dt * 0.5f);
+   const float vhy = v.y + (a.y * dt * 0.5f);
+   const float vhz = v.z + (a.z * dt * 0.5f);
+   const float nx0 = x.x + (vhx * pos_dt);
+   const float ny0 = x.y + (vhy * pos_dt);
+   const float nz0 = x.z + (vhz * pos_dt);
+
+   float rsx = (nx0 - k.cx), rsy = (ny0 - k.cy), rsz = (nz0 - k.cz);
+   if (!UNIT_SCALE) {
+      rsx *= k.sim_scale;
+      rsy *= k.sim_scale;
+      rsz *= k.sim_scale;
+   }
+   float dot = rsx * rsx + rsy * rsy + rsz * rsz;
+   dot = sqrtf(dot);
+   const float ds = dot + k.softening;
+   const float d3 = ds * ds * ds;
+   const float gm = -k.grav_const * k.central_mass;
+   float agx = gm * (rsx / d3), agy = gm * (rsy / d3), agz = gm * (rsz / d3);
+   if (k.apply_gravity) { // extension, as in accel_end
+      agx += k.gx;
+      agy += k.gy;
+      agz += k.gz;
+   }
+   float nvx = vhx + (agx * dt);
+   float nvy = vhy + (agy * dt);
+   float nvz = vhz + (agz * dt);
+   float nx = nx0, ny = ny0, nz = nz0;
+   if (k.apply_walls) { // extension: the reference's own (unwired) wall handling
+      const float pos[3] = {x.x, x.y, x.z};
+      float nv[3] = {nvx, nvy, nvz}, np[3] = {nx, ny, nz};
+      handle_boundaries(k, pos, nv, dt, np);
+      nvx = nv[0]; nvy = nv[1]; nvz = nv[2];
+      nx = np[0]; ny = np[1]; nz = np[2];
+   }
+
+   dot = nvx * nvx + nvy * nvy + nvz * nvz;
+   ke = 0.0;
+   pe = 0.0;
+   if (dot > 0) {
+      ke = (double)(0.5f * x.w * dot);
+      pe = -(double)(k.grav_const * k.central_mass * x.w / d3);
+   }
+   x.x = nx; x.y = ny; x.z = nz;
+   v.x = nvx; v.y = nvy; v.z = nvz;
+}
+
+// KE/PE contributions are reduced per block in double (the reference's serial fp32 running sum
+// is order dependent).
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(RED_THREADS)
 k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* __restrict__ acc,
@@ -58,53 +114,7 @@ k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* 
    if (p < meta[META_OWN_END]) {
       float4 x = posm[p];
       float4 v = velp[p];
-      const float4 a = acc[p];
-      const float dt = k.dt;
-      const float pos_dt = dt * k.sim_scale_inv;
-
-      const float vhx = v.x + (a.x * dt * 0.5f);
-      const float vhy = v.y + (a.y * dt * 0.5f);
-      const float vhz = v.z + (a.z * dt * 0.5f);
-      const float nx0 = x.x + (vhx * pos_dt);
-      const float ny0 = x.y + (vhy * pos_dt);
-      const float nz0 = x.z + (vhz * pos_dt);
-
-      float rsx = (nx0 - k.cx), rsy = (ny0 - k.cy), rsz = (nz0 - k.cz);
-      if (!UNIT_SCALE) {
-         rsx *= k.sim_scale;
-         rsy *= k.sim_scale;
-         rsz *= k.sim_scale;
-      }
-      float dot = rsx * rsx + rsy * rsy + rsz * rsz;
-      dot = sqrtf(dot);
-      const float ds = dot + k.softening;
-      const float d3 = ds * ds * ds;
-      const float gm = -k.grav_const * k.central_mass;
-      float agx = gm * (rsx / d3), agy = gm * (rsy / d3), agz = gm * (rsz / d3);
-      if (k.apply_gravity) { // extension, as in accel_end
-         agx += k.gx;
-         agy += k.gy;
-         agz += k.gz;
-      }
-      float nvx = vhx + (agx * dt);
-      float nvy = vhy + (agy * dt);
-      float nvz = vhz + (agz * dt);
-      float nx = nx0, ny = ny0, nz = nz0;
-      if (k.apply_walls) { // extension: the reference's own (unwired) wall handling
-         const float pos[3] = {x.x, x.y, x.z};
-         float nv[3] = {nvx, nvy, nvz}, np[3] = {nx, ny, nz};
-         handle_boundaries(k, pos, nv, dt, np);
-         nvx = nv[0]; nvy = nv[1]; nvz = nv[2];
-         nx = np[0]; ny = np[1]; nz = np[2];
-      }
-
-      dot = nvx * nvx + nvy * nvy + nvz * nvz;
-      if (dot > 0) {
-         ke = (double)(0.5f * x.w * dot);
-         pe = -(double)(k.grav_const * k.central_mass * x.w / d3);
-      }
-      x.x = nx; x.y = ny; x.z = nz;
-      v.x = nvx; v.y = nvy; v.z = nvz;
+      integrate_particle<UNIT_SCALE>(k, x, v, acc[p], ke, pe);
       posm[p] = x;
       velp[p] = v;
    }

@@ -493,6 +493,20 @@ struct AccelLds {
 };
 static_assert(NLIST_CAP + 1 <= 2 * SPH_WAVE, "count histogram is scanned by one wave, two entries per lane");
 
+// The acceleration pass can be launched in two parts (early exchange): part 1 = the workgroups
+// that hold a particle of the owned planes next to a neighbouring slab (sorted ranges
+// [OWN_BEGIN, BND_LO_END) and [BND_HI_BEGIN, OWN_END)), part 2 = all others, part 0 = everything.
+__device__ __forceinline__ bool accel_part_has(int part, int p0, const int32_t* __restrict__ meta)
+{
+   if (part == 0) return true;
+   const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+   const int lo_end = min(meta[META_BND_LO_END], oe);
+   const int hi_begin = min(max(meta[META_BND_HI_BEGIN], lo_end), oe);
+   const int a = max(p0, ob), b = min(p0 + TILE_THREADS, oe);   // owned particles of the workgroup
+   const bool border = (a < lo_end && b > ob) || (b > hi_begin && a < oe);
+   return border == (part == 1);
+}
+
 template <bool UNIT_SCALE, bool UNIFORM_MASS>
 __global__ void __launch_bounds__(TILE_THREADS, ACCEL_BLOCKS)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
@@ -502,7 +516,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                    float4* __restrict__ acc, const TileDesc* __restrict__ desc,
                    const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow,
                    int tile_cap, const int32_t* __restrict__ tile_stats,
-                   const uint32_t* __restrict__ giveup)
+                   const uint32_t* __restrict__ giveup, int part)
 {
    __shared__ AccelLds L;
    float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
@@ -511,8 +525,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
    const int tid = threadIdx.x;
    const int p0 = begin + blockIdx.x * TILE_THREADS;
-   // nothing of its own to do for workgroups past the range or made of ghosts only
-   const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe);
+   // nothing of its own to do for workgroups past the range or made of ghosts only - nor, when
+   // the pass is launched in two parts (early exchange), for those of the other part
+   const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&
+                    accel_part_has(part, p0, meta);
    // 1: tile did not fit the density pass (on the give-up list), 2: a neighbour list overflowed
    const uint32_t gave_up = own ? nlist_overflow[blockIdx.x] : 1u;
    // Untiled work, one call site: [0] the first workgroups of the launch start with the
@@ -522,8 +538,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       int untiled_p[2] = {-1, -1};
       const bool listed = (int)blockIdx.x < tile_stats[TSTAT_GIVEUP_ACCEL];
       if (listed) {
-         const int gp = begin + (int)giveup[blockIdx.x] * TILE_THREADS + tid;
-         if (gp < end && gp >= ob && gp < oe) untiled_p[0] = gp;
+         const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
+         const int gp = g0 + tid;
+         if (gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta)) untiled_p[0] = gp;
       }
       if (gave_up == 2u) {
          const int pp = p0 + tid;

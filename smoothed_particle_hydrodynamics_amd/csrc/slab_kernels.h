@@ -7,9 +7,11 @@
 // (still ours) or as migrant (now theirs) — the receiver decides by the particle's plane.
 #pragma once
 
+#include "common_kernels.h"
 #include "sph_device.h"
 
 #define SLAB_HEADER_INTS 8
+#define SLAB_PACK_BLOCKS 512   // fixed grid of the early pack (grid-stride over the border planes)
 
 struct SlabMsg {
    int32_t header[SLAB_HEADER_INTS];
@@ -65,40 +67,91 @@ k_slab_pack(const float4* __restrict__ posm, float4* __restrict__ velp, int32_t*
    }
 }
 
-// Appends the records of one received message behind the current entries.  offset_slot:
-// meta word holding the first free entry; it is advanced by the message's count.
+// Early exchange: the same messages, built BEFORE the step's integrate has run, so that they
+// travel while the interior's acceleration is computed.  Covers only the owned planes next to a
+// neighbouring slab (sorted ranges [OWN_BEGIN, BND_LO_END) and [BND_HI_BEGIN, OWN_END), one plane
+// wider than the halo), whose acceleration is already known; each of their particles is
+// integrated here on the fly - the same arithmetic k_integrate applies to the state later - and
+// classified by its NEW plane exactly as k_slab_pack does.  The state is not touched: last step's
+// ghosts and departed particles are recognised by the next cell build from their sorted position
+// (k_hash_count), which also flags an interior particle that should have been sent.
+// Fixed grid, grid-stride; the last workgroup to finish publishes the record counts.
+template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
-k_slab_unpack(const SlabMsg* __restrict__ msg, float4* __restrict__ posm,
-              float4* __restrict__ velp, int32_t* __restrict__ meta, int first_free_word,
-              int capacity_entries, int msg_capacity)
+k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ velp,
+                  const float4* __restrict__ acc, int32_t* __restrict__ meta, PairConsts k,
+                  CellGrid g, SlabZone zone, SlabMsg* __restrict__ left,
+                  SlabMsg* __restrict__ right, int capacity)
 {
-   int count = msg->header[0];
-   if (count > msg_capacity) count = msg_capacity;  // sender flagged the overflow on its side
-   const int base = meta[first_free_word];
-   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= count) return;
-   if (base + i >= capacity_entries) {
-      atomicOr(&meta[META_ERRORS], 4);
-      return;
+   const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+   const int lo_end = min(meta[META_BND_LO_END], oe);
+   const int hi_begin = min(max(meta[META_BND_HI_BEGIN], lo_end), oe);
+   const int n_left = lo_end - ob, n_right = oe - hi_begin;
+   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_left + n_right;
+        q += gridDim.x * blockDim.x) {
+      const int p = q < n_left ? ob + q : hi_begin + (q - n_left);
+      float4 x = posm[p];
+      float4 v = velp[p];
+      if (__float_as_uint(v.w) == SPH_DEAD_ID) continue;
+      double ke, pe;
+      integrate_particle<UNIT_SCALE>(k, x, v, acc[p], ke, pe);
+      const int plane = cell_coord(x.z, g.inv, g.nz_global);
+      if (zone.have_left && plane < zone.lo + zone.halo) {
+         const int s = atomicAdd(&meta[META_MSG_LEFT], 1);
+         if (s < capacity) {
+            left->rec[2 * s] = x;
+            left->rec[2 * s + 1] = v;
+         } else {
+            atomicOr(&meta[META_ERRORS], 2);
+         }
+      }
+      if (zone.have_right && plane >= zone.hi - zone.halo) {
+         const int s = atomicAdd(&meta[META_MSG_RIGHT], 1);
+         if (s < capacity) {
+            right->rec[2 * s] = x;
+            right->rec[2 * s + 1] = v;
+         } else {
+            atomicOr(&meta[META_ERRORS], 2);
+         }
+      }
    }
-   posm[base + i] = msg->rec[2 * i];
-   velp[base + i] = msg->rec[2 * i + 1];
+   // the last workgroup out writes the headers (k_scatter zeroed the three counters)
+   __threadfence();
+   __syncthreads();
+   if (threadIdx.x == 0 && atomicAdd(&meta[META_PACK_DONE], 1) == (int)gridDim.x - 1) {
+      __threadfence();
+      const int nl = atomicAdd(&meta[META_MSG_LEFT], 0), nr = atomicAdd(&meta[META_MSG_RIGHT], 0);
+      if (left) {
+         left->header[0] = nl;
+         left->header[1] = capacity;
+      }
+      if (right) {
+         right->header[0] = nr;
+         right->header[1] = capacity;
+      }
+   }
 }
 
-// n_in = n_live (+ counts of the messages just appended); one thread.
-__global__ void k_slab_set_n_in(int32_t* __restrict__ meta, const SlabMsg* __restrict__ a,
-                                const SlabMsg* __restrict__ b, int capacity_entries,
-                                int msg_capacity, int stage)
+// Appends the records of the received messages behind the live entries [0, n_live) and sets
+// n_in, the entry count of the next cell build.  One launch for both messages.
+__global__ void __launch_bounds__(256)
+k_slab_unpack(const SlabMsg* __restrict__ left, const SlabMsg* __restrict__ right,
+              float4* __restrict__ posm, float4* __restrict__ velp, int32_t* __restrict__ meta,
+              int capacity_entries, int msg_capacity)
 {
-   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-   // stage 0: n_in = n_live; stage 1: += count(a); stage 2: += count(b)
-   if (stage == 0) meta[META_N_IN] = meta[META_N_LIVE];
-   const SlabMsg* m = stage == 1 ? a : (stage == 2 ? b : nullptr);
-   if (m) {
-      int c = m->header[0];
-      if (c > msg_capacity) c = msg_capacity;
-      int v = meta[META_N_IN] + c;
-      if (v > capacity_entries) v = capacity_entries;
-      meta[META_N_IN] = v;
+   const int base = meta[META_N_LIVE];
+   const int cl = left ? min(left->header[0], msg_capacity) : 0;   // senders flag overflows
+   const int cr = right ? min(right->header[0], msg_capacity) : 0;
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < cl + cr) {
+      const SlabMsg* m = i < cl ? left : right;
+      const int r = i < cl ? i : i - cl;
+      if (base + i >= capacity_entries) {
+         atomicOr(&meta[META_ERRORS], 4);
+      } else {
+         posm[base + i] = m->rec[2 * r];
+         velp[base + i] = m->rec[2 * r + 1];
+      }
    }
+   if (i == 0) meta[META_N_IN] = min(base + cl + cr, capacity_entries);
 }

@@ -41,7 +41,25 @@ enum {
    META_SUM_BEGIN = 4, // sorted range whose density is needed (planes [lo-1, hi+1))
    META_SUM_END = 5,
    META_ERRORS = 6,    // bit 0: entry outside slab+halo, bit 1: message overflow, bit 2: capacity
-   META_COUNT = 8
+   // early exchange (sph_hip_slab_step_begin): sorted ranges [OWN_BEGIN, BND_LO_END) and
+   // [BND_HI_BEGIN, OWN_END) hold the owned planes next to a neighbouring slab, whose particles are
+   // integrated and packed before the interior's acceleration runs; message record counters
+   META_BND_LO_END = 7,
+   META_BND_HI_BEGIN = 8,
+   META_MSG_LEFT = 9,
+   META_MSG_RIGHT = 10,
+   META_PACK_DONE = 11, // workgroups of k_slab_pack_early that have finished
+   META_COUNT = 12
+};
+
+// What a slab's cell build needs to know about the exchange (by value in kernarg).
+struct SlabZone {
+   int lo, hi;          // owned global planes [lo, hi)
+   int halo;            // planes sent to / held from a neighbour
+   int have_left, have_right;
+   int drop_ghosts;     // FULL mode: entries of the previous sorted order outside its owned range
+                        // are last step's ghosts - dropped, their owner re-sends them
+   int early;           // the previous step packed its messages early: check nothing was missed
 };
 
 // Per-step statistics of the LDS tiles (k_tile_desc), fed back to the host's choice of tile
@@ -127,6 +145,7 @@ struct sph_hip_context {
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
+   int early_exchange = 0;         // the last step packed its messages early (sph_hip_slab_step_begin)
    int timing_level = 2;           // SPH_HIP_TIMING_*: which events sph_hip_step() records
    // LDS tile capacity of the two tiled kernels: chosen per launch among the largest tiles that
    // still allow B workgroups per CU (levels, ascending), from the tile size recent steps needed

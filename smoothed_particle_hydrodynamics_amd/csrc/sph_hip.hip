@@ -197,6 +197,20 @@ void pick_tile_caps(sph_hip_context* ctx)
               fb[TSTAT_BLOCKS], fb[TSTAT_MAX], caps.cap_density, caps.cap_accel);
 }
 
+// what the cell build has to know about the slab's neighbours
+SlabZone slab_zone(const sph_hip_context* ctx)
+{
+   SlabZone z;
+   z.lo = ctx->plane_lo;
+   z.hi = ctx->plane_hi;
+   z.halo = ctx->halo;
+   z.have_left = ctx->plane_lo > 0;
+   z.have_right = ctx->plane_hi < ctx->grid.nz_global;
+   z.drop_ghosts = ctx->mode == SPH_HIP_MODE_FULL;
+   z.early = ctx->early_exchange;
+   return z;
+}
+
 int launch_cell_build(sph_hip_context* ctx)
 {
    const int n = ctx->n;  // host upper bound of entries; the exact count is meta[META_N_IN]
@@ -205,14 +219,16 @@ int launch_cell_build(sph_hip_context* ctx)
    const CellGrid g = ctx->grid;
    hipStream_t st = ctx->stream;
    const int cur = ctx->cur;
+   const SlabZone zone = slab_zone(ctx);
    if (ctx->mode == SPH_HIP_MODE_REF)
       hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
-                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
+                         ctx->velp[cur], ctx->meta, g, zone, ctx->key, ctx->slot, ctx->cell_count,
                          ctx->vox);
    else
       hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
-                         ctx->velp[cur], ctx->meta, g, ctx->key, ctx->slot, ctx->cell_count,
+                         ctx->velp[cur], ctx->meta, g, zone, ctx->key, ctx->slot, ctx->cell_count,
                          (int32_t*)nullptr);
+   ctx->early_exchange = 0;  // consumed: it described the step before this build
    // the scan covers the real cells plus the trash cell, so cell_start[ncells] = live entries
    const int tiles = ctx->scan_tiles;
    const int ncells_scan = g.ncells + 1;
@@ -225,9 +241,14 @@ int launch_cell_build(sph_hip_context* ctx)
    const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
    const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
    const int sum_hi = own_hi + 1 > g.nz ? g.nz : own_hi + 1;
+   // owned planes next to a neighbouring slab, one wider than the halo (early exchange): a
+   // particle further inside cannot reach the planes that are sent within one step
+   const int border = ctx->halo + 1;
+   const int bnd_lo = !zone.have_left ? own_lo : (own_lo + border < own_hi ? own_lo + border : own_hi);
+   const int bnd_hi = !zone.have_right ? own_hi : (own_hi - border > own_lo ? own_hi - border : own_lo);
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
                       ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
-                      sum_lo, sum_hi, ctx->tile_stats);
+                      sum_lo, sum_hi, bnd_lo, bnd_hi, ctx->tile_stats);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
                          ctx->cell_start, ctx->meta, ctx->order);
@@ -288,7 +309,7 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
 #undef SPH_GO
 }
 
-void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
+void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part)
 {
    const int cap = ctx->caps.cap_accel;
    const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
@@ -297,7 +318,7 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
                       ctx->stream, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
                       ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
-                      ctx->giveup_accel)
+                      ctx->giveup_accel, part)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -332,7 +353,9 @@ int launch_density(sph_hip_context* ctx)
    return SPH_HIP_OK;
 }
 
-int launch_accel(sph_hip_context* ctx)
+// part: 0 = all workgroups; 1 / 2 = those with / without particles of the owned planes next to
+// a neighbouring slab (early exchange; tiled FULL mode only)
+int launch_accel(sph_hip_context* ctx, int part = 0)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
@@ -346,7 +369,7 @@ int launch_accel(sph_hip_context* ctx)
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         launch_accel_lists(ctx, unit, blocks, k);
+         launch_accel_lists(ctx, unit, blocks, k, part);
       } else if (unit) {
          hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
@@ -840,6 +863,7 @@ int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_devic
    if (rc) return rc;
    if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
    hipStream_t st = ctx->stream;
+   ctx->early_exchange = 0;  // this pack sees every particle after the integrate
    if (left_device) SPH_TRY(hipMemsetAsync(left_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
    if (right_device) SPH_TRY(hipMemsetAsync(right_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
    hipLaunchKernelGGL(k_slab_pack, dim3(div_up(ctx->n, 256)), dim3(256), 0, st, ctx->posm[ctx->cur],
@@ -856,20 +880,73 @@ int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const voi
    int rc = check_ctx(ctx);
    if (rc) return rc;
    if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
-   hipStream_t st = ctx->stream;
-   const SlabMsg* msgs[2] = {(const SlabMsg*)left_device, (const SlabMsg*)right_device};
-   // entries behind the live ones: start from n_in = n_live, append one message after the other
-   hipLaunchKernelGGL(k_slab_set_n_in, dim3(1), dim3(1), 0, st, ctx->meta, msgs[0], msgs[1],
-                      ctx->capacity, capacity_records, 0);
-   for (int s = 0; s < 2; s++) {
-      if (!msgs[s]) continue;
-      hipLaunchKernelGGL(k_slab_unpack, dim3(div_up(capacity_records, 256)), dim3(256), 0, st,
-                         msgs[s], ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->meta,
-                         (int)META_N_IN, ctx->capacity, capacity_records);
-      hipLaunchKernelGGL(k_slab_set_n_in, dim3(1), dim3(1), 0, st, ctx->meta, msgs[0], msgs[1],
-                         ctx->capacity, capacity_records, s + 1);
-   }
+   // entries behind the live ones; n_in = n_live + what the messages hold
+   hipLaunchKernelGGL(k_slab_unpack, dim3(div_up(2 * capacity_records, 256) + 1), dim3(256), 0,
+                      ctx->stream, (const SlabMsg*)left_device, (const SlabMsg*)right_device,
+                      ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->meta, ctx->capacity,
+                      capacity_records);
    SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right_device,
+                            int capacity_records)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
+   if (!ctx->use_tiled) {
+      ctx->err = "sph_hip_slab_step_begin: needs the tiled kernels (SPH_HIP_UNTILED is set)";
+      return SPH_HIP_ERR_INVALID;
+   }
+   if ((left_device != nullptr) != (ctx->plane_lo > 0) ||
+       (right_device != nullptr) != (ctx->plane_hi < ctx->grid.nz_global)) {
+      ctx->err = "sph_hip_slab_step_begin: one message buffer per existing neighbour, no other";
+      return SPH_HIP_ERR_INVALID;
+   }
+   hipStream_t st = ctx->stream;
+   hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
+   const int level = ctx->timing_level;
+   const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
+   if (phases) SPH_TRY(hipEventRecord(ev[0], st));
+   if ((rc = launch_cell_build(ctx))) return rc;
+   if (phases || sums) SPH_TRY(hipEventRecord(ev[1], st));
+   if ((rc = launch_density(ctx))) return rc;
+   if (phases) SPH_TRY(hipEventRecord(ev[3], st));
+   if (ctx->n == 0) return SPH_HIP_OK;
+   if ((rc = launch_accel(ctx, 1))) return rc;
+   const PairConsts k = pair_consts(ctx->prm);
+   const SlabZone zone = slab_zone(ctx);
+   if (unit_scale(ctx->prm))
+      hipLaunchKernelGGL(k_slab_pack_early<true>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, st,
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k, ctx->grid,
+                         zone, (SlabMsg*)left_device, (SlabMsg*)right_device, capacity_records);
+   else
+      hipLaunchKernelGGL(k_slab_pack_early<false>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, st,
+                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k, ctx->grid,
+                         zone, (SlabMsg*)left_device, (SlabMsg*)right_device, capacity_records);
+   SPH_TRY(hipGetLastError());
+   ctx->early_exchange = 1;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_step_end(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || !ctx->early_exchange) {
+      if (ctx) ctx->err = "sph_hip_slab_step_end: no sph_hip_slab_step_begin before it";
+      return SPH_HIP_ERR_INVALID;
+   }
+   hipStream_t st = ctx->stream;
+   hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
+   const int level = ctx->timing_level;
+   const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
+   if ((rc = launch_accel(ctx, 2))) return rc;
+   if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
+   if ((rc = launch_integrate(ctx))) return rc;
+   if (phases) SPH_TRY(hipEventRecord(ev[6], st));
+   if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;
    return SPH_HIP_OK;
 }
 

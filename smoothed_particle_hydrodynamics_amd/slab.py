@@ -146,6 +146,17 @@ class HipSlab:
     def step(self):
         self._check(self._lib.sph_hip_step(self._ctx), "sph_hip_step")
 
+    def step_begin(self):
+        """Cell build, density, acceleration of the planes next to a neighbour, messages packed
+        into send_left / send_right (sph_hip_slab_step_begin)."""
+        self._check(self._lib.sph_hip_slab_step_begin(self._ctx, self._dp(self.send_left),
+                                                      self._dp(self.send_right), self.msg_capacity),
+                    "sph_hip_slab_step_begin")
+
+    def step_end(self):
+        """Acceleration of the interior, integrate (sph_hip_slab_step_end)."""
+        self._check(self._lib.sph_hip_slab_step_end(self._ctx), "sph_hip_slab_step_end")
+
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
 
@@ -221,13 +232,18 @@ def slab_capacities(counts_per_plane, cuts, rank, slack=1.5):
 class DistTransport:
     """Neighbour exchange over torch.distributed point-to-point ops (RCCL when the backend is
     "nccl": each slab pair has its own xGMI link).  One batch per step: send left/right,
-    receive left/right."""
+    receive left/right.
+
+    exchange() orders the batch on the slab's own stream.  begin()/finish() put it on a separate
+    communication stream instead, behind an event recorded on the slab's stream, so that whatever
+    the slab enqueues between the two calls runs concurrently with the transfer."""
 
     def __init__(self, rank, world, group=None):
         import torch.distributed as dist
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
+        self._comm = None
 
-    def exchange(self, slab):
+    def _ops(self, slab):
         dist = self.dist
         ops = []
         left, right = self.rank - 1, self.rank + 1
@@ -237,22 +253,56 @@ class DistTransport:
         if right < self.world:
             ops.append(dist.P2POp(dist.isend, slab.send_right, right, self.group))
             ops.append(dist.P2POp(dist.irecv, slab.recv_right, right, self.group))
-        if not ops:
-            return
+        return ops
+
+    def _run(self, ops):
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()          # with RCCL: the current stream waits, the host does not
+
+    def exchange(self, slab):
         stream = getattr(slab, "stream", None)
         if stream is not None:
             import torch
             with torch.cuda.stream(stream):   # RCCL work is ordered against the slab's stream
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+                self._run(self._ops(slab))
         else:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            self._run(self._ops(slab))
+
+    def begin(self, slab):
+        """Start the exchange of the messages the slab's stream has packed so far."""
+        stream = getattr(slab, "stream", None)
+        if stream is None:                    # CPU stand-in: nothing to overlap with
+            self._run(self._ops(slab))
+            return
+        import torch
+        if self._comm is None:
+            with torch.cuda.device(slab.device):
+                self._comm = torch.cuda.Stream()
+                self._packed, self._arrived = torch.cuda.Event(), torch.cuda.Event()
+        self._packed.record(stream)
+        self._comm.wait_event(self._packed)
+        with torch.cuda.stream(self._comm):
+            self._run(self._ops(slab))
+            self._arrived.record(self._comm)
+
+    def finish(self, slab):
+        """The slab's stream waits for the exchange started by begin()."""
+        stream = getattr(slab, "stream", None)
+        if stream is not None and self._comm is not None:
+            stream.wait_event(self._arrived)
 
 
 class HostStagedTransport(DistTransport):
     """Same exchange with the messages staged through host memory (for process groups without
-    device-to-device P2P, e.g. gloo; used to rehearse the multi-rank path on one GPU)."""
+    device-to-device P2P, e.g. gloo; used to rehearse the multi-rank path on one GPU).
+    Synchronous: begin() does the whole exchange, finish() nothing."""
+
+    def begin(self, slab):
+        self.exchange(slab)
+
+    def finish(self, slab):
+        pass
 
     def exchange(self, slab):
         import torch
@@ -280,16 +330,39 @@ class HostStagedTransport(DistTransport):
 
 
 class DistSlabStepper:
-    """The per-rank loop body: pack -> exchange -> unpack -> step."""
+    """The per-rank loop body.
 
-    def __init__(self, slab, transport):
+    overlap=False: pack -> exchange -> unpack -> step, all on one stream.
+    overlap=True (default): after one such exchange has delivered the first ghosts,
+        step_begin (messages of the planes next to the neighbours are ready early)
+        -> exchange on the communication stream  ||  step_end (interior acceleration, integrate)
+        -> unpack.
+    Both leave the same state behind a step, except that the overlapped loop has already
+    exchanged the ghosts for the next one."""
+
+    def __init__(self, slab, transport, overlap=True):
         self.slab, self.transport = slab, transport
+        self.overlap = overlap and hasattr(slab, "step_begin")
+        self._primed = False
 
     def step(self):
-        self.slab.pack()
-        self.transport.exchange(self.slab)
-        self.slab.unpack()
-        self.slab.step()
+        slab, tr = self.slab, self.transport
+        if not self.overlap:
+            slab.pack()
+            tr.exchange(slab)
+            slab.unpack()
+            slab.step()
+            return
+        if not self._primed:
+            slab.pack()
+            tr.exchange(slab)
+            slab.unpack()
+            self._primed = True
+        slab.step_begin()
+        tr.begin(slab)
+        slab.step_end()
+        tr.finish(slab)
+        slab.unpack()
 
 
 class LocalSlabGroup:
@@ -297,18 +370,35 @@ class LocalSlabGroup:
     Same kernels and message format as the distributed run; used to check on a single GPU that
     results do not depend on the number of slabs."""
 
-    def __init__(self, slabs):
+    def __init__(self, slabs, overlap=False):
         self.slabs = slabs
+        self.overlap = overlap       # the early-exchange protocol (sph_hip_slab_step_begin/end)
+        self._primed = False
 
-    def step(self):
-        for s in self.slabs:
-            s.pack()
+    def _deliver(self):
         for r, s in enumerate(self.slabs):
             left = self.slabs[r - 1].send_right if r > 0 else None
             right = self.slabs[r + 1].send_left if r + 1 < len(self.slabs) else None
             s.unpack(left, right)
+
+    def step(self):
+        if not self.overlap:
+            for s in self.slabs:
+                s.pack()
+            self._deliver()
+            for s in self.slabs:
+                s.step()
+            return
+        if not self._primed:
+            for s in self.slabs:
+                s.pack()
+            self._deliver()
+            self._primed = True
         for s in self.slabs:
-            s.step()
+            s.step_begin()
+        for s in self.slabs:
+            s.step_end()
+        self._deliver()
 
     def gather(self, n_total):
         """Per-id arrays assembled from every slab's owned particles."""

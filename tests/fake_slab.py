@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: a CPU stand-in for smoothed_particle_hydrodynamics_amd.slab.HipSlab.
 
-Same five methods (upload / pack / unpack / step / download) and the same message format
+Same methods (upload / pack / unpack / step / step_begin / step_end / download) and the same message format
 (8 int32 header words + 32-byte records), with the step computed by the oracle.  It lets the
 slab orchestration (planning, message flow, torch.distributed transport) run on CPU tensors
 under gloo.  It lives under tests/ because it calls the oracle; the product never imports it.
@@ -104,13 +104,25 @@ class FakeSlab:
         sel = is_owned[order]
         self.owned = dict(ids=allp["ids"][order][sel], pos=pos.reshape(-1, 3)[sel],
                           vel=vel.reshape(-1, 3)[sel], mass=mass[sel])
-        self.last = dict(rho=out["rho"][sel], acc=out["acc"].reshape(-1, 3)[sel],
-                         ncount=out["ncount"][sel])
+        # what download() returns: the particles this slab owned during the step (as the HIP slab,
+        # whose owned range is that of the step's cell build)
+        self.last = dict(ids=self.owned["ids"].copy(), pos=self.owned["pos"].copy(),
+                         vel=self.owned["vel"].copy(), rho=out["rho"][sel],
+                         acc=out["acc"].reshape(-1, 3)[sel], ncount=out["ncount"][sel])
         self.ghosts = None
 
+    def step_begin(self):
+        """Early-exchange protocol: the messages are ready before the step has finished.  Here
+        the whole step simply runs first; what matters is the order of calls the stepper makes."""
+        self.step()
+        self.pack()
+
+    def step_end(self):
+        pass
+
     def download(self):
-        o, l = self.owned, self.last
-        return dict(ids=o["ids"], pos=o["pos"].reshape(-1), vel=o["vel"].reshape(-1),
+        l = self.last
+        return dict(ids=l["ids"], pos=l["pos"].reshape(-1), vel=l["vel"].reshape(-1),
                     rho=l["rho"], acc=l["acc"].reshape(-1), ncount=l["ncount"])
 
     def status(self):

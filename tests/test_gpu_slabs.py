@@ -12,7 +12,7 @@ from helpers import to_oracle_params
 pytestmark = pytest.mark.gpu
 
 
-def build_group(S, p, pos, vel, mass, world):
+def build_group(S, p, pos, vel, mass, world, overlap=False):
     from smoothed_particle_hydrodynamics_amd import slab as SL
     z = pos.reshape(-1, 3)[:, 2]
     cuts = SL.plan_cuts(p, z, world)
@@ -27,7 +27,7 @@ def build_group(S, p, pos, vel, mass, world):
                        has_right=r + 1 < world, stream=stream)
         s.upload(*SL.split_scene(p, cuts, r, pos, vel, mass), all_masses_equal=uniform)
         slabs.append(s)
-    return SL.LocalSlabGroup(slabs), cuts
+    return SL.LocalSlabGroup(slabs, overlap=overlap), cuts
 
 
 def moving_block(n=30000, speed=40.0, unequal=True):
@@ -38,12 +38,15 @@ def moving_block(n=30000, speed=40.0, unequal=True):
     return p, pos, vel, mass
 
 
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "early-exchange"])
 @pytest.mark.parametrize("world", [1, 2, 3, 4])
-def test_slabs_equal_single_context_and_oracle(oracle, hiplib, world):
+def test_slabs_equal_single_context_and_oracle(oracle, hiplib, world, overlap):
+    """overlap=True: the messages are packed before the interior's acceleration and the integrate
+    (sph_hip_slab_step_begin / _end) - what the distributed run overlaps with the transfer."""
     import smoothed_particle_hydrodynamics_amd as S
     p, pos, vel, mass = moving_block()
     steps = 5
-    group, cuts = build_group(S, p, pos, vel, mass, world)
+    group, cuts = build_group(S, p, pos, vel, mass, world, overlap)
     owned0 = [s.status()["owned"] for s in group.slabs]
     for _ in range(steps):
         group.step()
@@ -76,12 +79,13 @@ def test_slabs_equal_single_context_and_oracle(oracle, hiplib, world):
         s.close()
 
 
-def test_slabs_dam_break_uniform_mass_two_slabs(oracle, hiplib):
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "early-exchange"])
+def test_slabs_dam_break_uniform_mass_two_slabs(oracle, hiplib, overlap):
     """the benchmark scene (uniform masses -> fast path), 2 slabs, 3 steps"""
     import smoothed_particle_hydrodynamics_amd as S
     from smoothed_particle_hydrodynamics_amd import scenes
     p, pos, vel, mass = scenes.dam_break(120000)
-    group, cuts = build_group(S, p, pos, vel, mass, 2)
+    group, cuts = build_group(S, p, pos, vel, mass, 2, overlap)
     for _ in range(3):
         group.step()
     got = group.gather(mass.size)
@@ -113,4 +117,25 @@ def test_message_overflow_is_reported(hiplib):
     SL.LocalSlabGroup(slabs).step()
     assert any(s.status()["errors"] & 2 for s in slabs)
     for s in slabs:
+        s.close()
+
+
+def test_early_exchange_reports_a_particle_it_missed(hiplib):
+    """A particle deep inside a slab that jumps into the planes next to the border within one step
+    was not in the early message; the next cell build must say so (error bit 8), not lose it."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    p, pos, vel, mass = moving_block(20000, speed=0.0, unequal=False)
+    cuts = SL.plan_cuts(p, pos.reshape(-1, 3)[:, 2], 2)
+    pl = SL.plane_of(p, pos.reshape(-1, 3)[:, 2])
+    # one particle of slab 0, five planes below the cut, flies up five cell planes per step
+    i = int(np.nonzero(pl == cuts[1] - 6)[0][0])
+    cell = 1.0 / float(p.full_cell_inv)
+    vel = vel.copy()
+    vel.reshape(-1, 3)[i, 2] = 5.0 * cell / (float(p.time_step) * float(p.sim_scale_inv))
+    group, _ = build_group(S, p, pos, vel, mass, 2, overlap=True)
+    group.step()
+    group.step()
+    assert group.slabs[0].status()["errors"] & 8
+    for s in group.slabs:
         s.close()

@@ -64,7 +64,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, outdir):
+def _worker(rank, world, port, steps, outdir, overlap):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -79,7 +79,8 @@ def _worker(rank, world, port, steps, outdir):
         cuts = plan_cuts(p, pos.reshape(-1, 3)[:, 2], world)
         slab = FakeSlab(o, p, cuts[rank], cuts[rank + 1], 8192, rank > 0, rank + 1 < world)
         slab.upload(*split_scene(p, cuts, rank, pos, vel, mass), all_masses_equal=False)
-        stepper = DistSlabStepper(slab, DistTransport(rank, world))
+        stepper = DistSlabStepper(slab, DistTransport(rank, world), overlap=overlap)
+        assert stepper.overlap == overlap
         owned_history = []
         for _ in range(steps):
             stepper.step()
@@ -91,11 +92,12 @@ def _worker(rank, world, port, steps, outdir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "early-exchange"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_distributed_slabs_equal_single_domain(oracle, tmp_path, world):
+def test_distributed_slabs_equal_single_domain(oracle, tmp_path, world, overlap):
     steps = 4
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, steps, str(tmp_path), overlap), nprocs=world, join=True)
 
     p = oracle.params_for_h(0.1)
     pos, vel, mass = scene()
