@@ -220,7 +220,7 @@ int sph_hip_download_neighbor_lists(sph_hip_context* ctx, uint32_t* neighbors, f
  *     sph_hip_slab_step_begin   cell build, density, acceleration of the owned planes next to a
  *                               neighbour (halo + 1 planes), and the two messages: those
  *                               particles are integrated on the fly, the state is not touched
- *     <transport>               on ANOTHER stream, after an event recorded behind step_begin
+ *     <transport>               on the exchange stream handed to step_begin
  *     sph_hip_slab_step_end     acceleration of all other workgroups, integrate - concurrent
  *                               with the transport
  *     sph_hip_slab_unpack       after the context's stream has waited for the transport
@@ -246,9 +246,13 @@ int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_devic
                       int capacity_records);
 int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const void* right_device,
                         int capacity_records);
-/* See above.  Message buffers: exactly one per existing neighbour (NULL otherwise). */
+/* See above.  Message buffers: exactly one per existing neighbour (NULL otherwise).
+ * exchange_stream: the HIP stream the transport will be issued on (NULL = the context's stream,
+ * no overlap).  The border planes' acceleration and the packing are enqueued on it, behind the
+ * density pass, so the messages are complete in that stream's order and the work runs next to
+ * the interior's acceleration; sph_hip_slab_step_end makes the integrate wait for it. */
 int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right_device,
-                            int capacity_records);
+                            int capacity_records, void* exchange_stream);
 int sph_hip_slab_step_end(sph_hip_context* ctx);
 /* Diagnostics (synchronises): live entries, owned particles, error bits (1: a received entry
  * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded,

@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(256)
 k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
           const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
           uint32_t* __restrict__ perm, int cells_per_plane, int ncells, int own_lo, int own_hi,
-          int sum_lo, int sum_hi, int bnd_lo, int bnd_hi, int32_t* __restrict__ tile_stats)
+          int sum_lo, int sum_hi, int bnd_lo, int bnd_hi, int32_t* __restrict__ tile_stats,
+          int32_t* __restrict__ clear_a, int32_t* __restrict__ clear_b)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    // tile statistics of the step: the descriptor pass accumulates into them
@@ -227,7 +228,10 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
       meta[META_SUM_END] = (int)cell_start[sum_hi * cells_per_plane];
       meta[META_BND_LO_END] = (int)cell_start[bnd_lo * cells_per_plane];
       meta[META_BND_HI_BEGIN] = (int)cell_start[bnd_hi * cells_per_plane];
-      meta[META_MSG_LEFT] = meta[META_MSG_RIGHT] = meta[META_PACK_DONE] = 0;
+      // record counters of the messages this step will pack early (their previous contents
+      // have been sent: the stream waited for that transfer before the last unpack)
+      if (clear_a) *clear_a = 0;
+      if (clear_b) *clear_b = 0;
       if (tile_stats)   // 256-particle workgroups of the density range
          tile_stats[TSTAT_BLOCKS] = (meta[META_SUM_END] - meta[META_SUM_BEGIN] + 255) / 256;
    }

@@ -75,7 +75,9 @@ k_slab_pack(const float4* __restrict__ posm, float4* __restrict__ velp, int32_t*
 // classified by its NEW plane exactly as k_slab_pack does.  The state is not touched: last step's
 // ghosts and departed particles are recognised by the next cell build from their sorted position
 // (k_hash_count), which also flags an interior particle that should have been sent.
-// Fixed grid, grid-stride; the last workgroup to finish publishes the record counts.
+// Fixed grid, grid-stride.  The record counters are the headers' count words themselves, zeroed
+// by this step's k_scatter (a "last workgroup publishes the count" scheme needs a device-scope
+// fence per workgroup, which on this multi-L2 chip is an L2 write-back: it cost 60 us).
 template <bool UNIT_SCALE>
 __global__ void __launch_bounds__(256)
 k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ velp,
@@ -97,7 +99,7 @@ k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ ve
       integrate_particle<UNIT_SCALE>(k, x, v, acc[p], ke, pe);
       const int plane = cell_coord(x.z, g.inv, g.nz_global);
       if (zone.have_left && plane < zone.lo + zone.halo) {
-         const int s = atomicAdd(&meta[META_MSG_LEFT], 1);
+         const int s = atomicAdd(&left->header[0], 1);
          if (s < capacity) {
             left->rec[2 * s] = x;
             left->rec[2 * s + 1] = v;
@@ -106,7 +108,7 @@ k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ ve
          }
       }
       if (zone.have_right && plane >= zone.hi - zone.halo) {
-         const int s = atomicAdd(&meta[META_MSG_RIGHT], 1);
+         const int s = atomicAdd(&right->header[0], 1);
          if (s < capacity) {
             right->rec[2 * s] = x;
             right->rec[2 * s + 1] = v;
@@ -115,20 +117,9 @@ k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ ve
          }
       }
    }
-   // the last workgroup out writes the headers (k_scatter zeroed the three counters)
-   __threadfence();
-   __syncthreads();
-   if (threadIdx.x == 0 && atomicAdd(&meta[META_PACK_DONE], 1) == (int)gridDim.x - 1) {
-      __threadfence();
-      const int nl = atomicAdd(&meta[META_MSG_LEFT], 0), nr = atomicAdd(&meta[META_MSG_RIGHT], 0);
-      if (left) {
-         left->header[0] = nl;
-         left->header[1] = capacity;
-      }
-      if (right) {
-         right->header[0] = nr;
-         right->header[1] = capacity;
-      }
+   if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (left) left->header[1] = capacity;
+      if (right) right->header[1] = capacity;
    }
 }
 

@@ -43,12 +43,9 @@ enum {
    META_ERRORS = 6,    // bit 0: entry outside slab+halo, bit 1: message overflow, bit 2: capacity
    // early exchange (sph_hip_slab_step_begin): sorted ranges [OWN_BEGIN, BND_LO_END) and
    // [BND_HI_BEGIN, OWN_END) hold the owned planes next to a neighbouring slab, whose particles are
-   // integrated and packed before the interior's acceleration runs; message record counters
+   // integrated and packed before the interior's acceleration runs
    META_BND_LO_END = 7,
    META_BND_HI_BEGIN = 8,
-   META_MSG_LEFT = 9,
-   META_MSG_RIGHT = 10,
-   META_PACK_DONE = 11, // workgroups of k_slab_pack_early that have finished
    META_COUNT = 12
 };
 
@@ -146,6 +143,9 @@ struct sph_hip_context {
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
    int early_exchange = 0;         // the last step packed its messages early (sph_hip_slab_step_begin)
+   hipStream_t border_stream = nullptr; // stream the last step_begin put the border work on
+   hipEvent_t ev_density = nullptr; // early exchange: density done (main stream) -> border work may start
+   hipEvent_t ev_border = nullptr;  //                 border acceleration done (exchange stream) -> integrate may run
    int timing_level = 2;           // SPH_HIP_TIMING_*: which events sph_hip_step() records
    // LDS tile capacity of the two tiled kernels: chosen per launch among the largest tiles that
    // still allow B workgroups per CU (levels, ascending), from the tile size recent steps needed

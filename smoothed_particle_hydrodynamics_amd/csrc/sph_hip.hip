@@ -84,6 +84,8 @@ void free_all(sph_hip_context* ctx)
          if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
       delete[] ctx->ev;
    }
+   if (ctx->ev_density) (void)hipEventDestroy(ctx->ev_density);
+   if (ctx->ev_border) (void)hipEventDestroy(ctx->ev_border);
    if (ctx->tile_feedback) (void)hipHostFree(ctx->tile_feedback);
    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 }
@@ -211,7 +213,8 @@ SlabZone slab_zone(const sph_hip_context* ctx)
    return z;
 }
 
-int launch_cell_build(sph_hip_context* ctx)
+// clear_left/right: message buffers whose record counters this build zeroes (early exchange)
+int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* clear_right = nullptr)
 {
    const int n = ctx->n;  // host upper bound of entries; the exact count is meta[META_N_IN]
    if (n == 0) return SPH_HIP_OK;
@@ -248,7 +251,8 @@ int launch_cell_build(sph_hip_context* ctx)
    const int bnd_hi = !zone.have_right ? own_hi : (own_hi - border > own_lo ? own_hi - border : own_lo);
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
                       ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
-                      sum_lo, sum_hi, bnd_lo, bnd_hi, ctx->tile_stats);
+                      sum_lo, sum_hi, bnd_lo, bnd_hi, ctx->tile_stats, (int32_t*)clear_left,
+                      (int32_t*)clear_right);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
                          ctx->cell_start, ctx->meta, ctx->order);
@@ -309,13 +313,14 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
 #undef SPH_GO
 }
 
-void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part)
+void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part,
+                        hipStream_t st)
 {
    const int cap = ctx->caps.cap_accel;
    const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
 #define SPH_GO(U, M)                                                                             \
    hipLaunchKernelGGL((k_full_accel_lists<U, M>), dim3(blocks), dim3(TILE_THREADS), lds,         \
-                      ctx->stream, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
+                      st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
                       ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
                       ctx->giveup_accel, part)
@@ -355,7 +360,7 @@ int launch_density(sph_hip_context* ctx)
 
 // part: 0 = all workgroups; 1 / 2 = those with / without particles of the owned planes next to
 // a neighbouring slab (early exchange; tiled FULL mode only)
-int launch_accel(sph_hip_context* ctx, int part = 0)
+int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = nullptr)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
@@ -369,7 +374,7 @@ int launch_accel(sph_hip_context* ctx, int part = 0)
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         launch_accel_lists(ctx, unit, blocks, k, part);
+         launch_accel_lists(ctx, unit, blocks, k, part, part ? part_stream : ctx->stream);
       } else if (unit) {
          hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
@@ -611,6 +616,8 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(hipMemsetAsync(ctx->tile_stats, 0, TSTAT_COUNT * sizeof(int32_t), ctx->stream));
       CREATE_TRY(dev_alloc(&ctx->giveup_density, (size_t)div_up(capacity, TILE_THREADS) + 1));
       CREATE_TRY(dev_alloc(&ctx->giveup_accel, (size_t)div_up(capacity, TILE_THREADS) + 1));
+      CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_density, hipEventDisableTiming));
+      CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_border, hipEventDisableTiming));
       if (const char* v = getenv("SPH_HIP_TILE_CAP")) {
          const int c = atoi(v);
          if (c > 0) ctx->tile_cap_forced = c < 256 ? 256 : (c > 3008 ? 3008 : c / 32 * 32);  // 48 KiB at most
@@ -890,7 +897,7 @@ int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const voi
 }
 
 int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right_device,
-                            int capacity_records)
+                            int capacity_records, void* exchange_stream)
 {
    int rc = check_ctx(ctx);
    if (rc) return rc;
@@ -905,28 +912,37 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
       return SPH_HIP_ERR_INVALID;
    }
    hipStream_t st = ctx->stream;
+   hipStream_t side = exchange_stream ? (hipStream_t)exchange_stream : st;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
    const int level = ctx->timing_level;
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
    if (phases) SPH_TRY(hipEventRecord(ev[0], st));
-   if ((rc = launch_cell_build(ctx))) return rc;
+   if ((rc = launch_cell_build(ctx, left_device, right_device))) return rc;
    if (phases || sums) SPH_TRY(hipEventRecord(ev[1], st));
    if ((rc = launch_density(ctx))) return rc;
    if (phases) SPH_TRY(hipEventRecord(ev[3], st));
+   ctx->early_exchange = 1;
    if (ctx->n == 0) return SPH_HIP_OK;
-   if ((rc = launch_accel(ctx, 1))) return rc;
+   // border work on the exchange stream, behind the density pass: it runs next to the interior's
+   // acceleration (sph_hip_slab_step_end, main stream) and is short, so the messages leave early
+   if (side != st) {
+      SPH_TRY(hipEventRecord(ctx->ev_density, st));
+      SPH_TRY(hipStreamWaitEvent(side, ctx->ev_density, 0));
+   }
+   if ((rc = launch_accel(ctx, 1, side))) return rc;
    const PairConsts k = pair_consts(ctx->prm);
    const SlabZone zone = slab_zone(ctx);
    if (unit_scale(ctx->prm))
-      hipLaunchKernelGGL(k_slab_pack_early<true>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, st,
+      hipLaunchKernelGGL(k_slab_pack_early<true>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, side,
                          ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k, ctx->grid,
                          zone, (SlabMsg*)left_device, (SlabMsg*)right_device, capacity_records);
    else
-      hipLaunchKernelGGL(k_slab_pack_early<false>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, st,
+      hipLaunchKernelGGL(k_slab_pack_early<false>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, side,
                          ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k, ctx->grid,
                          zone, (SlabMsg*)left_device, (SlabMsg*)right_device, capacity_records);
    SPH_TRY(hipGetLastError());
-   ctx->early_exchange = 1;
+   if (side != st) SPH_TRY(hipEventRecord(ctx->ev_border, side));
+   ctx->border_stream = side;
    return SPH_HIP_OK;
 }
 
@@ -935,15 +951,17 @@ int sph_hip_slab_step_end(sph_hip_context* ctx)
    int rc = check_ctx(ctx);
    if (rc) return rc;
    if (ctx->mode != SPH_HIP_MODE_FULL || !ctx->early_exchange) {
-      if (ctx) ctx->err = "sph_hip_slab_step_end: no sph_hip_slab_step_begin before it";
+      ctx->err = "sph_hip_slab_step_end: no sph_hip_slab_step_begin before it";
       return SPH_HIP_ERR_INVALID;
    }
    hipStream_t st = ctx->stream;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
    const int level = ctx->timing_level;
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
-   if ((rc = launch_accel(ctx, 2))) return rc;
+   if ((rc = launch_accel(ctx, 2, st))) return rc;
    if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
+   // the integrate needs the border planes' acceleration (and must not move them under the pack)
+   if (ctx->n > 0 && ctx->border_stream != st) SPH_TRY(hipStreamWaitEvent(st, ctx->ev_border, 0));
    if ((rc = launch_integrate(ctx))) return rc;
    if (phases) SPH_TRY(hipEventRecord(ev[6], st));
    if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;

@@ -146,11 +146,14 @@ class HipSlab:
     def step(self):
         self._check(self._lib.sph_hip_step(self._ctx), "sph_hip_step")
 
-    def step_begin(self):
+    def step_begin(self, exchange_stream=None):
         """Cell build, density, acceleration of the planes next to a neighbour, messages packed
-        into send_left / send_right (sph_hip_slab_step_begin)."""
+        into send_left / send_right (sph_hip_slab_step_begin).  exchange_stream: torch stream the
+        transport will run on; the border work is enqueued there (None: the slab's stream)."""
+        ptr = C.c_void_p(exchange_stream.cuda_stream) if exchange_stream is not None else None
         self._check(self._lib.sph_hip_slab_step_begin(self._ctx, self._dp(self.send_left),
-                                                      self._dp(self.send_right), self.msg_capacity),
+                                                      self._dp(self.send_right), self.msg_capacity,
+                                                      ptr),
                     "sph_hip_slab_step_begin")
 
     def step_end(self):
@@ -234,9 +237,10 @@ class DistTransport:
     "nccl": each slab pair has its own xGMI link).  One batch per step: send left/right,
     receive left/right.
 
-    exchange() orders the batch on the slab's own stream.  begin()/finish() put it on a separate
-    communication stream instead, behind an event recorded on the slab's stream, so that whatever
-    the slab enqueues between the two calls runs concurrently with the transfer."""
+    exchange() orders the batch on the slab's own stream.  begin()/finish() put it on the
+    communication stream (comm_stream(): the stream handed to HipSlab.step_begin, which enqueues
+    the packing there), so that whatever the slab enqueues on its own stream between the two calls
+    runs concurrently with the transfer."""
 
     def __init__(self, rank, world, group=None):
         import torch.distributed as dist
@@ -269,22 +273,28 @@ class DistTransport:
         else:
             self._run(self._ops(slab))
 
+    def comm_stream(self, slab):
+        """The communication stream (high priority: its short border work should not queue behind
+        the interior's workgroups); None for a CPU stand-in."""
+        if getattr(slab, "stream", None) is None:
+            return None
+        if self._comm is None:
+            import torch
+            with torch.cuda.device(slab.device):
+                self._comm = torch.cuda.Stream(priority=-1)
+                self._arrived = torch.cuda.Event()
+        return self._comm
+
     def begin(self, slab):
-        """Start the exchange of the messages the slab's stream has packed so far."""
-        stream = getattr(slab, "stream", None)
-        if stream is None:                    # CPU stand-in: nothing to overlap with
+        """Start the exchange of the messages packed on the communication stream."""
+        comm = self.comm_stream(slab)
+        if comm is None:                      # CPU stand-in: nothing to overlap with
             self._run(self._ops(slab))
             return
         import torch
-        if self._comm is None:
-            with torch.cuda.device(slab.device):
-                self._comm = torch.cuda.Stream()
-                self._packed, self._arrived = torch.cuda.Event(), torch.cuda.Event()
-        self._packed.record(stream)
-        self._comm.wait_event(self._packed)
-        with torch.cuda.stream(self._comm):
+        with torch.cuda.stream(comm):
             self._run(self._ops(slab))
-            self._arrived.record(self._comm)
+            self._arrived.record(comm)
 
     def finish(self, slab):
         """The slab's stream waits for the exchange started by begin()."""
@@ -297,6 +307,9 @@ class HostStagedTransport(DistTransport):
     """Same exchange with the messages staged through host memory (for process groups without
     device-to-device P2P, e.g. gloo; used to rehearse the multi-rank path on one GPU).
     Synchronous: begin() does the whole exchange, finish() nothing."""
+
+    def comm_stream(self, slab):
+        return None          # everything on the slab's stream
 
     def begin(self, slab):
         self.exchange(slab)
@@ -358,7 +371,11 @@ class DistSlabStepper:
             tr.exchange(slab)
             slab.unpack()
             self._primed = True
-        slab.step_begin()
+        comm = tr.comm_stream(slab)
+        if comm is not None:
+            slab.step_begin(comm)
+        else:
+            slab.step_begin()
         tr.begin(slab)
         slab.step_end()
         tr.finish(slab)
@@ -370,9 +387,12 @@ class LocalSlabGroup:
     Same kernels and message format as the distributed run; used to check on a single GPU that
     results do not depend on the number of slabs."""
 
-    def __init__(self, slabs, overlap=False):
+    def __init__(self, slabs, overlap=False, exchange_stream=None):
         self.slabs = slabs
         self.overlap = overlap       # the early-exchange protocol (sph_hip_slab_step_begin/end)
+        # optional second stream for the border work, as in the distributed run (the messages
+        # are then complete in ITS order, and the slabs' stream has to wait for it)
+        self.exchange_stream = exchange_stream
         self._primed = False
 
     def _deliver(self):
@@ -395,9 +415,11 @@ class LocalSlabGroup:
             self._deliver()
             self._primed = True
         for s in self.slabs:
-            s.step_begin()
+            s.step_begin(self.exchange_stream)
         for s in self.slabs:
             s.step_end()
+        if self.exchange_stream is not None:
+            self.slabs[0].stream.wait_stream(self.exchange_stream)
         self._deliver()
 
     def gather(self, n_total):

@@ -27,7 +27,9 @@ def build_group(S, p, pos, vel, mass, world, overlap=False):
                        has_right=r + 1 < world, stream=stream)
         s.upload(*SL.split_scene(p, cuts, r, pos, vel, mass), all_masses_equal=uniform)
         slabs.append(s)
-    return SL.LocalSlabGroup(slabs, overlap=overlap), cuts
+    two = overlap == "two-streams"
+    return SL.LocalSlabGroup(slabs, overlap=bool(overlap),
+                             exchange_stream=torch.cuda.Stream(priority=-1) if two else None), cuts
 
 
 def moving_block(n=30000, speed=40.0, unequal=True):
@@ -38,7 +40,8 @@ def moving_block(n=30000, speed=40.0, unequal=True):
     return p, pos, vel, mass
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "early-exchange"])
+@pytest.mark.parametrize("overlap", [False, True, "two-streams"],
+                         ids=["serial", "early-exchange", "early-exchange-2-streams"])
 @pytest.mark.parametrize("world", [1, 2, 3, 4])
 def test_slabs_equal_single_context_and_oracle(oracle, hiplib, world, overlap):
     """overlap=True: the messages are packed before the interior's acceleration and the integrate
@@ -79,7 +82,8 @@ def test_slabs_equal_single_context_and_oracle(oracle, hiplib, world, overlap):
         s.close()
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "early-exchange"])
+@pytest.mark.parametrize("overlap", [False, True, "two-streams"],
+                         ids=["serial", "early-exchange", "early-exchange-2-streams"])
 def test_slabs_dam_break_uniform_mass_two_slabs(oracle, hiplib, overlap):
     """the benchmark scene (uniform masses -> fast path), 2 slabs, 3 steps"""
     import smoothed_particle_hydrodynamics_amd as S
