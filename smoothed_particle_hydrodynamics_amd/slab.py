@@ -248,6 +248,15 @@ class DistTransport:
         self._comm = None
 
     def _ops(self, slab):
+        # the message buffers of a slab never change: build the op list once per slab
+        cached = getattr(self, "_op_cache", None)
+        if cached is not None and cached[0] is slab:
+            return cached[1]
+        ops = self._build_ops(slab)
+        self._op_cache = (slab, ops)
+        return ops
+
+    def _build_ops(self, slab):
         dist = self.dist
         ops = []
         left, right = self.rank - 1, self.rank + 1
