@@ -219,16 +219,16 @@ __device__ __forceinline__ void tile_load(const float4* __restrict__ posm, const
 #else
    for (int base = 0; base < total; base += TILE_BATCH * TILE_THREADS) {
 #endif
+      // unconditional loads (index clamped into the tile): a load inside a divergent branch gets
+      // its own s_waitcnt from the compiler, which serialises the whole batch
       float4 buf[TILE_BATCH];
 #pragma unroll
       for (int r = 0; r < TILE_BATCH; r++) {
-         const int idx = base + tid + r * TILE_THREADS;
-         if (idx < total) {
-            int d = D[0];
+         const int idx = min(base + tid + r * TILE_THREADS, total - 1);
+         int d = D[0];
 #pragma unroll
-            for (int k = 1; k < 9; k++) d = (idx >= B[k]) ? D[k] : d;
-            buf[r] = posm[idx - d];
-         }
+         for (int k = 1; k < 9; k++) d = (idx >= B[k]) ? D[k] : d;
+         buf[r] = posm[idx - d];
       }
 #pragma unroll
       for (int r = 0; r < TILE_BATCH; r++) {
@@ -383,6 +383,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          // append the set bits, ascending, to the lane's neighbour list: an even entry waits in
          // a register, an odd one completes a 32-bit word and stores it (half the scattered
          // stores); words past NLIST_CAP all land in the spare row (workgroup flagged, redone)
+#if defined(SPH_ABLATE) && SPH_ABLATE == 9
+         count += __builtin_popcount(mask);   // timing only: no lists
+         mask = 0u;
+#endif
          while (__any(mask != 0u)) {
 #pragma unroll
             for (int rep = 0; rep < APPEND_POPS; rep++) {   // several pops per trip: less loop control
@@ -571,18 +575,17 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          D[kk] = L.desc.D[kk];
       }
       for (int base = 0; base < total; base += TILE_BATCH * TILE_THREADS) {
+         // unconditional loads, index clamped into the tile (see tile_load)
          float4 buf[TILE_BATCH];
          float cbuf[TILE_BATCH];
 #pragma unroll
          for (int r = 0; r < TILE_BATCH; r++) {
-            const int idx = base + tid + r * TILE_THREADS;
-            if (idx < total) {
-               int d = D[0];
+            const int idx = min(base + tid + r * TILE_THREADS, total - 1);
+            int d = D[0];
 #pragma unroll
-               for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
-               buf[r] = posm[idx - d];
-               cbuf[r] = auxc[idx - d];
-            }
+            for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
+            buf[r] = posm[idx - d];
+            cbuf[r] = auxc[idx - d];
          }
 #pragma unroll
          for (int r = 0; r < TILE_BATCH; r++) {
