@@ -193,12 +193,23 @@ k_rank_gather_tile_desc(int desc_blocks, int ntiles, const uint32_t* __restrict_
                g.ncells, posm_in, velp_in, posm_out, velp_out);
 }
 
-__device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, TileDesc& sd)
+__device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, int wg, TileDesc& sd)
 {
    const int tid = threadIdx.x;
    if (tid < (int)(sizeof(TileDesc) / sizeof(int)))
-      reinterpret_cast<int*>(&sd)[tid] = reinterpret_cast<const int*>(&desc[blockIdx.x])[tid];
+      reinterpret_cast<int*>(&sd)[tid] = reinterpret_cast<const int*>(&desc[wg])[tid];
    __syncthreads();
+}
+
+// Which 256-particle workgroup a hardware workgroup computes.  The dispatcher deals consecutive
+// blockIdx round-robin over the 8 XCDs, each with its own L2, while neighbouring workgroups share
+// most of their tile (each sorted particle is staged by ~6 workgroups): give every residue class
+// of blockIdx mod 8 a contiguous eighth of the workgroups, so the shared rows hit one L2.
+// Bijective for any grid size.  Only a placement hint: results do not depend on it.
+__device__ __forceinline__ int xcd_workgroup(int block, int nblocks)
+{
+   const int q = nblocks / 8, r = nblocks % 8, x = block % 8;
+   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + block / 8;
 }
 
 // Copies the candidate positions of the workgroup's tile into LDS, TILE_BATCH 16-byte loads per
@@ -318,7 +329,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          density_untiled<UNIT_SCALE>(gp, posm, cell_start, velp, g, k, rho_out, velB_out, auxc_out,
                                      ncount);
    }
-   const int p0 = begin + blockIdx.x * TILE_THREADS;
+   const int wg = xcd_workgroup(blockIdx.x, gridDim.x);
+   const int p0 = begin + wg * TILE_THREADS;
    if (p0 >= end) return;
    const int p = p0 + tid;
    const bool live = p < end;
@@ -328,10 +340,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    // out before the tile's loads, so that both are in flight together.
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
    if (live) pi = posm[p];
-   tile_desc_load(desc, sd);
+   tile_desc_load(desc, wg, sd);
    if (sd.total > tile_cap) {
       // tile does not fit: on the give-up lists, computed by the first workgroups of both passes
-      if (tid == 0) nlist_overflow[blockIdx.x] = 1u;
+      if (tid == 0) nlist_overflow[wg] = 1u;
       return;
    }
    RowRanges r;
@@ -348,7 +360,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const int self_t = p + sd.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
    // uniform base of the workgroup's list block; lanes address it with 32-bit offsets
-   uint32_t* list_block = nlist + (size_t)blockIdx.x * (NLIST_WORDS * TILE_THREADS);
+   uint32_t* list_block = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS);
    const uint32_t* my_list = list_block + tid;
 
    int count = 0;
@@ -411,7 +423,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    if (count > NLIST_CAP) list_overflow = 1;
    __syncthreads();
    const int give_up = list_overflow;
-   if (tid == 0) nlist_overflow[blockIdx.x] = give_up ? 2u : 0u;
+   if (tid == 0) nlist_overflow[wg] = give_up ? 2u : 0u;
    float density = 0.0f;
    if (give_up) {
       // Some particle of the workgroup has more than NLIST_CAP neighbours (a scene several times
@@ -528,13 +540,14 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
    const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
    const int tid = threadIdx.x;
-   const int p0 = begin + blockIdx.x * TILE_THREADS;
+   const int wg = xcd_workgroup(blockIdx.x, gridDim.x);
+   const int p0 = begin + wg * TILE_THREADS;
    // nothing of its own to do for workgroups past the range or made of ghosts only - nor, when
    // the pass is launched in two parts (early exchange), for those of the other part
    const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&
                     accel_part_has(part, p0, meta);
    // 1: tile did not fit the density pass (on the give-up list), 2: a neighbour list overflowed
-   const uint32_t gave_up = own ? nlist_overflow[blockIdx.x] : 1u;
+   const uint32_t gave_up = own ? nlist_overflow[wg] : 1u;
    // Untiled work, one call site: [0] the first workgroups of the launch start with the
    // workgroups whose tile does not fit (give-up list), so that their long latency overlaps the
    // rest of the launch; [1] a workgroup whose lists overflowed computes its own particles.
@@ -564,7 +577,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       const int pp = p0 + tid;
       if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
    }
-   tile_desc_load(desc, L.desc);
+   tile_desc_load(desc, wg, L.desc);
    const int total = L.desc.total;
    if (total > tile_cap) return;  // does not fit this pass's wider entries: on the give-up list
    {
@@ -636,7 +649,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    }
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
-   const uint32_t* my_list = nlist + (size_t)blockIdx.x * (NLIST_WORDS * TILE_THREADS) + col;
+   const uint32_t* my_list = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS) + col;
    // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
    // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
    // so neither of a neighbour's two dependent memory round trips is waited for in isolation.
