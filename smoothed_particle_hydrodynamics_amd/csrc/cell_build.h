@@ -232,8 +232,9 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
       // have been sent: the stream waited for that transfer before the last unpack)
       if (clear_a) *clear_a = 0;
       if (clear_b) *clear_b = 0;
-      if (tile_stats)   // 256-particle workgroups of the density range
-         tile_stats[TSTAT_BLOCKS] = (meta[META_SUM_END] - meta[META_SUM_BEGIN] + 255) / 256;
+      if (tile_stats)   // workgroups of the density range
+         tile_stats[TSTAT_BLOCKS] =
+            (meta[META_SUM_END] - meta[META_SUM_BEGIN] + TILE_THREADS - 1) / TILE_THREADS;
    }
 }
 

@@ -25,7 +25,6 @@
 
 #include "full_kernels.h"
 
-#define TILE_THREADS 256
 // The tile lives in dynamic LDS: its capacity (candidate positions per workgroup) is a launch
 // parameter, chosen by the host from the tile sizes the previous steps needed, because the
 // workgroups a CU can hold (and with them the latency hiding of both passes) is set by the LDS
@@ -36,8 +35,8 @@
 #define DENSITY_TILE_BYTES 12
 #define ACCEL_TILE_BYTES 16
 // launch bounds = the most workgroups per CU the register budget should allow
-#define DENSITY_BLOCKS 6
-#define ACCEL_BLOCKS 5
+#define DENSITY_BLOCKS (6 * 256 / TILE_THREADS)
+#define ACCEL_BLOCKS (TILE_THREADS == 256 ? 5 : 2)
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
 // NLIST_WORDS rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
 // reads/writes 256 contiguous bytes).  Only rows in use are ever touched.

@@ -62,6 +62,10 @@ struct SlabZone {
 // Per-step statistics of the LDS tiles (k_tile_desc), fed back to the host's choice of tile
 // capacity: how many workgroups would not fit each candidate capacity.
 #define TILE_CANDS 8
+// particles (= threads) of one workgroup of the tiled FULL-mode passes
+#ifndef TILE_THREADS
+#define TILE_THREADS 256
+#endif
 enum {
    TSTAT_OVER = 0,          // [TILE_CANDS] workgroups whose tile exceeds candidate i
    TSTAT_BLOCKS = 8,        // workgroups counted

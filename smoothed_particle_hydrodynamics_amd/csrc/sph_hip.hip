@@ -157,7 +157,7 @@ int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, int
          if (levels[l] >= 3008) return levels[l];
       return levels[n - 1];
    }
-   const int tolerated = blocks >= 8192 ? blocks / 512 : 0;
+   const int tolerated = blocks >= 8192 * 256 / TILE_THREADS ? blocks / 512 : 0;
    for (int l = 0; l < n; l++)
       for (int c = 0; c < ctx->caps.n_cand; c++)
          if (ctx->caps.cand[c] == levels[l] && fb[TSTAT_OVER + c] <= tolerated) return levels[l];
@@ -343,7 +343,7 @@ int launch_density(sph_hip_context* ctx)
    } else {
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
-         launch_density_tiled(ctx, unit, blocks, k);  // give-up workgroups fall back inline
+         launch_density_tiled(ctx, unit, div_up(n, TILE_THREADS), k);  // give-up workgroups fall back inline
       } else if (unit) {                               // SPH_HIP_UNTILED=1: untiled everywhere
          hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
@@ -374,7 +374,7 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         launch_accel_lists(ctx, unit, blocks, k, part, part ? part_stream : ctx->stream);
+         launch_accel_lists(ctx, unit, div_up(n, TILE_THREADS), k, part, part ? part_stream : ctx->stream);
       } else if (unit) {
          hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
