@@ -38,9 +38,10 @@ def parse_args():
                          "(one unit box per slab); strong = --particles in total, unit box")
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1: skip the shorter measurement of the other scaling mode")
-    ap.add_argument("--cpu-sample", type=int, default=131072,
-                    help="particles in the CPU-baseline sample (0 disables)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=524288,
+                    help="particles in the CPU-baseline sample (0 disables); with --cpu-steps "
+                         "sized for ~10 s of single-thread work")
+    ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
 
 
@@ -69,6 +70,60 @@ def cpu_baseline(n_sample, steps, n_total):
         "sample": "%d-particle slice of the same dam-break column (same density, h, %.1f "
                   "neighbours/particle), %d FULL-mode steps, %.1f s; host has %d cores" % (
                       n_sample, float(out["ncount"].mean()), steps, dt, os.cpu_count()),
+    }
+
+
+def reference_scene(S, steps=8, n=32768):
+    """The reference's own compiled src/sph.cpp (oracle/_ref, built where /root/reference exists
+    and shipped as a .so) timed on this box on ITS default scene - srand(42) sphere, 32 768
+    particles, shipped sampled neighbour search, one thread like the original - next to the HIP
+    library in REF mode on the same initial state, with a live check that both end in the same
+    bits.  None when the reference build is not present."""
+    import ctypes as C
+    from oracle import oracle as orc
+    if not orc.reference_available():
+        return None
+    p = S.default_params()
+    op = orc.OracleParams()
+    C.memmove(C.byref(op), C.byref(p), C.sizeof(op))
+    ref = orc.Reference()
+    ref.configure(op, n)
+    ref.init_sphere()
+    s0 = ref.get_state()
+    ref.step()                                   # untimed: first touch
+    ref.set_state(s0["pos"], s0["vel"], s0["mass"])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ref.step()
+    dt_cpu = (time.perf_counter() - t0) / steps
+    s1 = ref.get_state()
+    with S.SPH(n, p, mode=S.MODE_REF) as sph:
+        sph.setParticles(s0["pos"], s0["vel"], s0["mass"])
+        for _ in range(steps):
+            sph.step()
+        part = sph.getParticles()
+        same = bool(np.array_equal(part.mPosition, s1["pos"]) and
+                    np.array_equal(part.mVelocity, s1["vel"]) and
+                    np.array_equal(part.mDensity, s1["rho"]) and
+                    np.array_equal(part.mNeighborCount, s1["ncount"]))
+        sph.setParticles(s0["pos"], s0["vel"], s0["mass"])
+        sph.setTiming(S.TIMING_OFF)
+        sph.run(5)
+        sph.synchronize()
+        k = 200
+        t0 = time.perf_counter()
+        sph.run(k)
+        sph.synchronize()
+        dt_gpu = (time.perf_counter() - t0) / k
+    return {
+        "workload": "the reference's default scene: srand(42) sphere, %d particles, shipped "
+                    "sampled neighbour search (REF mode)" % n,
+        "cpu": {"value": n / dt_cpu / 1e6, "unit": "Mparticle-steps/s", "ms_per_step": dt_cpu * 1e3,
+                "cores": 1, "kind": "reference",
+                "sample": "%d x SPH::step() of the compiled src/sph.cpp" % steps},
+        "gpu": {"value": n / dt_gpu / 1e6, "unit": "Mparticle-steps/s", "ms_per_step": dt_gpu * 1e3},
+        "speedup": dt_cpu / dt_gpu,
+        "identical_after_steps": steps if same else 0,
     }
 
 
@@ -303,6 +358,9 @@ def main():
             line["other_scaling"] = other
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
+            ref_scene = reference_scene(S)
+            if ref_scene is not None:
+                line["reference_scene"] = ref_scene
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
