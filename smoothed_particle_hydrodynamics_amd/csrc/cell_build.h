@@ -20,7 +20,9 @@
 // Lanes of a wave that hold consecutive particles of the same cell (the common case once the
 // state is cell-sorted) share ONE global atomic: the run's first lane adds the run length and
 // the others take base + their rank in the run.
-template <bool WRITE_VOX>
+// CHECK_DEAD: entries may carry the dead id (only sph_hip_slab_pack writes it); otherwise the
+// velocity/id array is not read at all.
+template <bool WRITE_VOX, bool CHECK_DEAD>
 __global__ void __launch_bounds__(256)
 k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
              int32_t* __restrict__ meta, CellGrid g, SlabZone zone, uint32_t* __restrict__ key,
@@ -40,7 +42,7 @@ k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
       const bool carried = zone.drop_ghosts && i < meta[META_N_LIVE];
       const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
       const bool was_owned = i >= ob && i < oe;
-      if (__float_as_uint(velp[i].w) == SPH_DEAD_ID) {
+      if (CHECK_DEAD && __float_as_uint(velp[i].w) == SPH_DEAD_ID) {
          c = (uint32_t)g.ncells;  // dropped ghost / departed particle
       } else if (carried && !was_owned) {
          c = (uint32_t)g.ncells;  // last step's ghost: its owner sends it again every step

@@ -146,6 +146,7 @@ struct sph_hip_context {
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
+   int may_hold_dead = 0;          // sph_hip_slab_pack has marked entries dead since the last cell build
    int early_exchange = 0;         // the last step packed its messages early (sph_hip_slab_step_begin)
    hipStream_t border_stream = nullptr; // stream the last step_begin put the border work on
    hipEvent_t ev_density = nullptr; // early exchange: density done (main stream) -> border work may start

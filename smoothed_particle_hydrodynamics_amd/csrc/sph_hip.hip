@@ -224,14 +224,19 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    const int cur = ctx->cur;
    const SlabZone zone = slab_zone(ctx);
    if (ctx->mode == SPH_HIP_MODE_REF)
-      hipLaunchKernelGGL(k_hash_count<true>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+      hipLaunchKernelGGL((k_hash_count<true, false>), dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
                          ctx->velp[cur], ctx->meta, g, zone, ctx->key, ctx->slot, ctx->cell_count,
                          ctx->vox);
+   else if (ctx->may_hold_dead)
+      hipLaunchKernelGGL((k_hash_count<false, true>), dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+                         ctx->velp[cur], ctx->meta, g, zone, ctx->key, ctx->slot, ctx->cell_count,
+                         (int32_t*)nullptr);
    else
-      hipLaunchKernelGGL(k_hash_count<false>, dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
+      hipLaunchKernelGGL((k_hash_count<false, false>), dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
                          ctx->velp[cur], ctx->meta, g, zone, ctx->key, ctx->slot, ctx->cell_count,
                          (int32_t*)nullptr);
    ctx->early_exchange = 0;  // consumed: it described the step before this build
+   ctx->may_hold_dead = 0;   // the build drops dead entries
    // the scan covers the real cells plus the trash cell, so cell_start[ncells] = live entries
    const int tiles = ctx->scan_tiles;
    const int ncells_scan = g.ncells + 1;
@@ -871,6 +876,7 @@ int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_devic
    if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
    hipStream_t st = ctx->stream;
    ctx->early_exchange = 0;  // this pack sees every particle after the integrate
+   ctx->may_hold_dead = 1;   // ... and marks the ones to drop with the dead id
    if (left_device) SPH_TRY(hipMemsetAsync(left_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
    if (right_device) SPH_TRY(hipMemsetAsync(right_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
    hipLaunchKernelGGL(k_slab_pack, dim3(div_up(ctx->n, 256)), dim3(256), 0, st, ctx->posm[ctx->cur],
