@@ -253,19 +253,27 @@ __device__ __forceinline__ void tile_load(const float4* __restrict__ posm, const
    __syncthreads();
 }
 
-// fp32 squared distances of two candidates at once: ((dx*dx) + (dy*dy)) + (dz*dz) per lane
-// element, same association and rounding as dist2() — packed ops round each half like the
-// scalar ops do.
-__device__ __forceinline__ f32x2 dist2_pair(f32x2 px, f32x2 py, f32x2 pz, f32x2 cx, f32x2 cy,
-                                            f32x2 cz)
+// TEST screens, SUM confirms.  The reference accepts a neighbour iff the fp32 value
+// ((dx*dx) + (dy*dy)) + (dz*dz), five separate roundings, is < h2.  TEST evaluates the sum with
+// two fused multiply-adds instead (6 packed ops per candidate pair instead of 8; the 8 ops were a
+// sixth of this pass's arithmetic) and compares it with h2 * (1 + 2e-6).  Near the threshold both
+// evaluations are within 2.5 + 1.5 ulp(h2) < 5e-7 * h2 of the true value, so every neighbour the
+// exact test accepts passes the screen; a candidate that passes it wrongly (about one in 10^6) is
+// caught by SUM, which needs the exact value of every listed pair for the distance anyway: it
+// leaves the pair out of the sum, and the lane then rewrites its list without it, so neighbour
+// lists and counts are exactly the reference's.
+
+// squared distances of two candidates at once, fused: for screening only
+__device__ __forceinline__ f32x2 dist2_pair_screen(f32x2 px, f32x2 py, f32x2 pz, f32x2 cx, f32x2 cy,
+                                                   f32x2 cz)
 {
    const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
-   return dx * dx + dy * dy + dz * dz;
+   return __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
 }
 
-// TEST step: eight consecutive, 32-byte aligned tile slots t..t+7 -> 8 acceptance bits.
-// Six independent ds_read_b128 and branch-free packed math; slots outside the lane's range
-// are masked by the caller.
+// TEST step: eight consecutive, 32-byte aligned tile slots t..t+7 -> 8 screening bits (h2 is the
+// widened threshold).  Six independent ds_read_b128 and branch-free packed math; slots outside
+// the lane's range are masked by the caller.
 __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32x2 py, f32x2 pz,
                                          float h2)
 {
@@ -275,10 +283,10 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
    const f32x4 Y1 = lds_read4(L.y, t + 4);
    const f32x4 Z0 = lds_read4(L.z, t);
    const f32x4 Z1 = lds_read4(L.z, t + 4);
-   const f32x2 a = dist2_pair(px, py, pz, f32x2{X0.x, X0.y}, f32x2{Y0.x, Y0.y}, f32x2{Z0.x, Z0.y});
-   const f32x2 b = dist2_pair(px, py, pz, f32x2{X0.z, X0.w}, f32x2{Y0.z, Y0.w}, f32x2{Z0.z, Z0.w});
-   const f32x2 c = dist2_pair(px, py, pz, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
-   const f32x2 d = dist2_pair(px, py, pz, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
+   const f32x2 a = dist2_pair_screen(px, py, pz, f32x2{X0.x, X0.y}, f32x2{Y0.x, Y0.y}, f32x2{Z0.x, Z0.y});
+   const f32x2 b = dist2_pair_screen(px, py, pz, f32x2{X0.z, X0.w}, f32x2{Y0.z, Y0.w}, f32x2{Z0.z, Z0.w});
+   const f32x2 c = dist2_pair_screen(px, py, pz, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
+   const f32x2 d = dist2_pair_screen(px, py, pz, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
    uint32_t m = 0;
    m |= (a.x < h2) ? 1u : 0u;
    m |= (a.y < h2) ? 2u : 0u;
@@ -360,8 +368,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
    // uniform base of the workgroup's list block; lanes address it with 32-bit offsets
    uint32_t* list_block = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS);
-   const uint32_t* my_list = list_block + tid;
 
+   const float h2_screen = k.h2_screen;
    int count = 0;
    uint32_t hold = 0;  // an even-numbered entry waiting for its partner
 #pragma unroll
@@ -378,10 +386,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 #else
          if (t0 < te) {
 #endif
-            mask = test8(L, t0, px, py, pz, k.h2);
-            if (t0 + 8 < te) mask |= test8(L, t0 + 8, px, py, pz, k.h2) << 8;
-            if (t0 + 16 < te) mask |= test8(L, t0 + 16, px, py, pz, k.h2) << 16;
-            if (t0 + 24 < te) mask |= test8(L, t0 + 24, px, py, pz, k.h2) << 24;
+            mask = test8(L, t0, px, py, pz, h2_screen);
+            if (t0 + 8 < te) mask |= test8(L, t0 + 8, px, py, pz, h2_screen) << 8;
+            if (t0 + 16 < te) mask |= test8(L, t0 + 16, px, py, pz, h2_screen) << 16;
+            if (t0 + 24 < te) mask |= test8(L, t0 + 24, px, py, pz, h2_screen) << 24;
             // keep only slots inside [ts, te), and not the particle itself
             const int lo = ts - t0, hi = te - t0;
             if (lo > 0) mask &= ~0u << lo;
@@ -458,6 +466,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    }
 
    // SUM: one pass over the list, in canonical order
+   const uint32_t* sum_list = list_block + tid;
+   bool screened_wrongly = false;
    for (int j0 = 0; !give_up && __any(j0 < count); j0 += DENSITY_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
       uint32_t entry[DENSITY_UNROLL];
@@ -465,7 +475,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u += 2) {
          const int w = ((j0 + u) >> 1) < lastw ? ((j0 + u) >> 1) : lastw;
-         const uint32_t word = my_list[w * TILE_THREADS];  // independent loads, all in flight
+         const uint32_t word = sum_list[w * TILE_THREADS];  // independent loads, all in flight
          entry[u] = word & 0xffffu;
          entry[u + 1] = word >> 16;
       }
@@ -477,12 +487,42 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             if (!UNIFORM_MASS) mj = posm[t - sd.D[entry[u] >> QUEUE_TBITS]].w;
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-            float d = sqrtf(d2);
-            if (!UNIT_SCALE) d *= k.sim_scale;
-            density_accumulate(k, mj, d, density);
+            if (d2 < k.h2) {             // the reference's own test, on the reference's own value
+               float d = sqrtf(d2);
+               if (!UNIT_SCALE) d *= k.sim_scale;
+               density_accumulate(k, mj, d, density);
+            } else {
+               screened_wrongly = true;  // passed the fused screen only: not a neighbour
+            }
          }
       }
 #endif
+   }
+   if (__any(screened_wrongly)) {
+      // about one lane in 10^4: rewrite the list without the pairs that are not neighbours (two
+      // entries per word in, two per word out; the write position never passes the read position)
+      if (screened_wrongly) {
+         int kept = 0;
+         uint32_t out_hold = 0;
+         for (int j = 0; j < count; j += 2) {
+            const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+               if (j + half < count) {
+                  const uint32_t entry = half ? word >> 16 : word & 0xffffu;
+                  const int t = (int)(entry & QUEUE_TMASK);
+                  float dx, dy, dz;
+                  if (dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz) < k.h2) {
+                     if (kept & 1) list_block[((uint32_t)kept >> 1) * TILE_THREADS + (uint32_t)tid] = out_hold | (entry << 16);
+                     else out_hold = entry;
+                     kept++;
+                  }
+               }
+            }
+         }
+         if (kept & 1) list_block[((uint32_t)kept >> 1) * TILE_THREADS + (uint32_t)tid] = out_hold;
+         count = kept;
+      }
    }
    if (live) {
       rho_out[p] = density;

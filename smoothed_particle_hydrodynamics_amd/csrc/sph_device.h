@@ -62,6 +62,8 @@ struct SlabZone {
 // Per-step statistics of the LDS tiles (k_tile_desc), fed back to the host's choice of tile
 // capacity: how many workgroups would not fit each candidate capacity.
 #define TILE_CANDS 8
+// density pass: widening of h2 for the fused screening test (csrc/full_tiled.h, "TEST screens")
+#define TEST_SCREEN_FACTOR 1.000002f
 // particles (= threads) of one workgroup of the tiled FULL-mode passes
 #ifndef TILE_THREADS
 #define TILE_THREADS 256
@@ -86,6 +88,7 @@ struct TileCaps {
 // Constants of the per-pair arithmetic, by value in kernarg (scalar registers).
 struct PairConsts {
    float h2, hscaled, hscaled2, sim_scale;
+   float h2_screen;   // h2 widened for the density pass's fused-multiply-add screening test
    float kernel1, kernel2, kernel3;
    float rho0, stiffness, viscosity;
    float grav_const, central_mass, cx, cy, cz, softening;

@@ -28,6 +28,11 @@ PairConsts pair_consts(const sph_hip_params& p)
 {
    PairConsts k;
    k.h2 = p.h2;
+   // SPH_HIP_TEST_SCREEN widens the screen (tests: many candidates then reach the exact
+   // confirmation and the list rewrite; the results must not change)
+   static const float screen = getenv("SPH_HIP_TEST_SCREEN") ? (float)atof(getenv("SPH_HIP_TEST_SCREEN"))
+                                                             : TEST_SCREEN_FACTOR;
+   k.h2_screen = p.h2 * (screen >= TEST_SCREEN_FACTOR ? screen : TEST_SCREEN_FACTOR);
    k.hscaled = p.hscaled;
    k.hscaled2 = p.hscaled2;
    k.sim_scale = p.sim_scale;
