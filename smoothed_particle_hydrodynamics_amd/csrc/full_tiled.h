@@ -256,19 +256,21 @@ __device__ __forceinline__ void tile_load(const float4* __restrict__ posm, const
 // TEST screens, SUM confirms.  The reference accepts a neighbour iff the fp32 value
 // ((dx*dx) + (dy*dy)) + (dz*dz), five separate roundings, is < h2.  TEST evaluates the sum with
 // two fused multiply-adds instead (6 packed ops per candidate pair instead of 8; the 8 ops were a
-// sixth of this pass's arithmetic) and compares it with h2 * (1 + 2e-6).  Near the threshold both
-// evaluations are within 2.5 + 1.5 ulp(h2) < 5e-7 * h2 of the true value, so every neighbour the
-// exact test accepts passes the screen; a candidate that passes it wrongly (about one in 10^6) is
+// sixth of this pass's arithmetic), with -h2 * (1 + 2e-6) as the innermost addend, and takes the
+// sign.  Near the threshold the two evaluations are within 2.5 + 1.5 ulp(h2) < 5e-7 * h2 of the
+// true value, so every neighbour the exact test accepts passes the screen; a candidate that passes it wrongly (about one in 10^6) is
 // caught by SUM, which needs the exact value of every listed pair for the distance anyway: it
 // leaves the pair out of the sum, and the lane then rewrites its list without it, so neighbour
 // lists and counts are exactly the reference's.
 
-// squared distances of two candidates at once, fused: for screening only
-__device__ __forceinline__ f32x2 dist2_pair_screen(f32x2 px, f32x2 py, f32x2 pz, f32x2 cx, f32x2 cy,
-                                                   f32x2 cz)
+// d2 - h2_screen of two candidates at once, three fused multiply-adds: for screening only (its
+// sign is the screening bit; the subtraction rides in the first FMA's addend)
+__device__ __forceinline__ f32x2 screen_pair(f32x2 px, f32x2 py, f32x2 pz, f32x2 cx, f32x2 cy,
+                                             f32x2 cz, f32x2 minus_h2)
 {
    const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
-   return __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+   return __builtin_elementwise_fma(
+      dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, minus_h2)));
 }
 
 // TEST step: eight consecutive, 32-byte aligned tile slots t..t+7 -> 8 screening bits (h2 is the
@@ -283,19 +285,22 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
    const f32x4 Y1 = lds_read4(L.y, t + 4);
    const f32x4 Z0 = lds_read4(L.z, t);
    const f32x4 Z1 = lds_read4(L.z, t + 4);
-   const f32x2 a = dist2_pair_screen(px, py, pz, f32x2{X0.x, X0.y}, f32x2{Y0.x, Y0.y}, f32x2{Z0.x, Z0.y});
-   const f32x2 b = dist2_pair_screen(px, py, pz, f32x2{X0.z, X0.w}, f32x2{Y0.z, Y0.w}, f32x2{Z0.z, Z0.w});
-   const f32x2 c = dist2_pair_screen(px, py, pz, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
-   const f32x2 d = dist2_pair_screen(px, py, pz, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
+   const f32x2 mh = {-h2, -h2};
+   const f32x2 da = screen_pair(px, py, pz, f32x2{X0.x, X0.y}, f32x2{Y0.x, Y0.y}, f32x2{Z0.x, Z0.y}, mh);
+   const f32x2 db = screen_pair(px, py, pz, f32x2{X0.z, X0.w}, f32x2{Y0.z, Y0.w}, f32x2{Z0.z, Z0.w}, mh);
+   const f32x2 dc = screen_pair(px, py, pz, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y}, mh);
+   const f32x2 dd = screen_pair(px, py, pz, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w}, mh);
+   // inside the screen  <=>  sign bit of (d2 - h2); v_alignbit shifts the mask left and brings the
+   // next sign in at bit 0 - slot 7 first, so that slot 0 ends in bit 0
    uint32_t m = 0;
-   m |= (a.x < h2) ? 1u : 0u;
-   m |= (a.y < h2) ? 2u : 0u;
-   m |= (b.x < h2) ? 4u : 0u;
-   m |= (b.y < h2) ? 8u : 0u;
-   m |= (c.x < h2) ? 16u : 0u;
-   m |= (c.y < h2) ? 32u : 0u;
-   m |= (d.x < h2) ? 64u : 0u;
-   m |= (d.y < h2) ? 128u : 0u;
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd.y), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd.x), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(dc.y), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(dc.x), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(db.y), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(db.x), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(da.y), 31);
+   m = __builtin_amdgcn_alignbit(m, __float_as_uint(da.x), 31);
    return m;
 }
 
