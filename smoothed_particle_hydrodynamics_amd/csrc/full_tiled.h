@@ -403,10 +403,16 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                const int sb = self_t - t0;
                if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
             }
+            // a list that would overflow stops growing here (checked per chunk, not per entry):
+            // the workgroup gives up its lists anyway
+            if (count + __builtin_popcount(mask) > NLIST_CAP) {
+               mask = 0u;
+               count = NLIST_CAP + 1;
+            }
          }
          // append the set bits, ascending, to the lane's neighbour list: an even entry waits in
          // a register, an odd one completes a 32-bit word and stores it (half the scattered
-         // stores); words past NLIST_CAP all land in the spare row (workgroup flagged, redone)
+         // stores)
 #if defined(SPH_ABLATE) && SPH_ABLATE == 9
          count += __builtin_popcount(mask);   // timing only: no lists
          mask = 0u;
@@ -419,8 +425,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                   mask &= mask - 1u;
                   const uint32_t entry = kbits | ((uint32_t)t0 + bit);
                   if (count & 1) {
-                     const uint32_t row = count < NLIST_CAP ? (uint32_t)count >> 1 : (uint32_t)(NLIST_CAP / 2);
-                     list_block[row * TILE_THREADS + (uint32_t)tid] = hold | (entry << 16);
+                     list_block[((uint32_t)count >> 1) * TILE_THREADS + (uint32_t)tid] = hold | (entry << 16);
                   } else {
                      hold = entry;
                   }
