@@ -698,6 +698,8 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    }
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
+   // every listed pair passed the exact d2 < h2 test: the division's range checks are uniform
+   const bool in_range = accel_operands_in_range(k);
    const uint32_t* my_list = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS) + col;
    // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
    // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
@@ -738,7 +740,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             float d = sqrtf(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
             accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
-                                   pj.w);
+                                   pj.w, in_range);
          }
       }
    }

@@ -38,12 +38,14 @@ __device__ __forceinline__ float2 neighbor_terms(const PairConsts& k, float rho_
 // the denominator alone, so it is done once and each quotient keeps its own last two steps:
 // the same operations on the same values, hence the same bits as three separate divisions.
 // den is in [0.01, 0.01 + h]; a non-finite numerator (positions that already blew up) takes the
-// plain division so that infinities propagate exactly like on the CPU.
+// plain division so that infinities propagate exactly like on the CPU.  in_range (uniform): the
+// caller has established that no operand can leave the range (see accel_operands_in_range), so
+// the per-pair checks are skipped.
 __device__ __forceinline__ void div3_shared_den(float nx, float ny, float nz, double den,
-                                                float& qx, float& qy, float& qz)
+                                                float& qx, float& qy, float& qz, bool in_range)
 {
-   if (__builtin_isfinite(nx) && __builtin_isfinite(ny) && __builtin_isfinite(nz) &&
-       den >= 0.0078125 && den <= 1.0e6) {
+   if (in_range || (__builtin_isfinite(nx) && __builtin_isfinite(ny) && __builtin_isfinite(nz) &&
+                    den >= 0.0078125 && den <= 1.0e6)) {
       double r = __builtin_amdgcn_rcp(den);
       double e = __builtin_fma(-den, r, 1.0);
       r = __builtin_fma(r, e, r);
@@ -84,12 +86,23 @@ __device__ __forceinline__ void accel_begin(const PairConsts& k, AccelState& s, 
    s.vtx = s.vty = s.vtz = 0.0f;
 }
 
+// For a pair that passed the exact test d2 < h2, with d2 computed from (dx,dy,dz): |dx|, |dy|, |dz|
+// and the distance are at most sqrt(h2); after scaling, the division's numerators are bounded by
+// |kernel2| * reach and its denominator lies in [0.01, 0.01 + reach] - the per-pair range checks of
+// div3_shared_den are decided by the constants alone.
+__device__ __forceinline__ bool accel_operands_in_range(const PairConsts& k)
+{
+   const float reach = sqrtf(k.h2) * k.sim_scale * 1.01f;
+   return k.sim_scale > 0.0f && __builtin_isfinite(reach) && reach <= 9.0e5f &&
+          __builtin_isfinite(k.kernel2 * reach);
+}
+
 // One neighbour (reference src/sph.cpp:846-882).  (dx,dy,dz) = r_i - r_j, d = stored distance,
-// B/C from neighbor_terms().
+// B/C from neighbor_terms().  in_range: see accel_operands_in_range (false = check every pair).
 template <bool UNIT_SCALE>
 __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, float dx, float dy,
                                            float dz, float d, float mj, float vjx, float vjy,
-                                           float vjz, float B, float C)
+                                           float vjz, float B, float C, bool in_range = false)
 {
    const float rsx = UNIT_SCALE ? dx : dx * k.sim_scale;
    const float rsy = UNIT_SCALE ? dy : dy * k.sim_scale;
@@ -97,7 +110,7 @@ __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, f
    // float product, double add, double divide, narrowed to float (:854-856)
    const double den = (double)d + 0.01;
    float gx, gy, gz;
-   div3_shared_den(k.kernel2 * rsx, k.kernel2 * rsy, k.kernel2 * rsz, den, gx, gy, gz);
+   div3_shared_den(k.kernel2 * rsx, k.kernel2 * rsy, k.kernel2 * rsz, den, gx, gy, gz, in_range);
 
    float center = (k.hscaled - d);
    center *= center;
