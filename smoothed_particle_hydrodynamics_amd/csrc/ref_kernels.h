@@ -69,14 +69,21 @@ k_ref_find_neighbors(const float4* __restrict__ posm, const int32_t* __restrict_
          // positions first .. first+7 must all lie in [0, len)
          if (first < 0 || first + (REF_CHUNK - 1) >= len) break;
          ii += REF_CHUNK;
+         // the four tested positions: indices first, then the four gathers, then the tests in
+         // order - two dependent round trips per chunk instead of eight
+         uint32_t q[4];
+         float4 pj[4];
+#pragma unroll
+         for (int j = 0; j < 4; j++) q[j] = order[start + (uint32_t)(first + j)];
+#pragma unroll
+         for (int j = 0; j < 4; j++) pj[j] = posm[q[j]];
+#pragma unroll
          for (int j = 0; j < 4; j++) {
-            const uint32_t q = order[start + (uint32_t)(first + j)];
-            if (q == (uint32_t)i) continue;
-            const float4 pj = posm[q];
+            if (q[j] == (uint32_t)i) continue;
             float dx, dy, dz;
-            const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
+            const float d2 = dist2(pi.x, pi.y, pi.z, pj[j].x, pj[j].y, pj[j].z, dx, dy, dz);
             if (d2 < h2) {
-               my_nb[count] = q;
+               my_nb[count] = q[j];
                my_nd[count] = sqrtf(d2) * sim_scale;
                count++;
             }
