@@ -107,10 +107,27 @@ k_ref_density(const float4* __restrict__ posm, const uint32_t* __restrict__ nb,
    const float* my_nd = nd + (size_t)i * cap;
    const int cnt = ncount[i];
    float density = 0.0f;
-   for (int kk = 0; kk < cnt; kk++) {
-      const uint32_t q = my_nb[kk];
-      if (q >= (uint32_t)n) break;
-      if (q != (uint32_t)i) density_accumulate(k, posm[q].w, my_nd[kk], density);
+   // four list entries per trip: their index loads, then their gathers, are issued together
+   // (positions past the count re-read the last entry; unused)
+   bool stop = false;
+   for (int k0 = 0; k0 < cnt && !stop; k0 += 4) {
+      uint32_t q[4];
+      float dj[4], mj[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const int kk = min(k0 + u, cnt - 1);
+         q[u] = my_nb[kk];
+         dj[u] = my_nd[kk];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) mj[u] = posm[min(q[u], (uint32_t)(n - 1))].w;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         if (k0 + u < cnt && !stop) {
+            if (q[u] >= (uint32_t)n) stop = true;
+            else if (q[u] != (uint32_t)i) density_accumulate(k, mj[u], dj[u], density);
+         }
+      }
    }
    rho[i] = density;
 }
@@ -130,13 +147,30 @@ k_ref_accel(const float4* __restrict__ posm, const float4* __restrict__ velp,
    const float4 pi = posm[i];
    AccelState s;
    accel_begin(k, s, pi, velp[i], rho[i]);
-   for (int kk = 0; kk < cnt; kk++) {
-      const uint32_t q = my_nb[kk];
-      const float4 pj = posm[q];
-      const float4 vj = velp[q];
-      const float2 bc = neighbor_terms(k, rho[q], pj.w);
-      accel_pair<false>(k, s, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, my_nd[kk], pj.w, vj.x, vj.y,
-                        vj.z, bc.x, bc.y);
+   for (int k0 = 0; k0 < cnt; k0 += 4) {   // as above: four entries' loads in flight together
+      uint32_t q[4];
+      float dj[4], rj[4];
+      float4 pj[4], vj[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const int kk = min(k0 + u, cnt - 1);
+         q[u] = my_nb[kk];
+         dj[u] = my_nd[kk];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         pj[u] = posm[q[u]];
+         vj[u] = velp[q[u]];
+         rj[u] = rho[q[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         if (k0 + u < cnt) {
+            const float2 bc = neighbor_terms(k, rj[u], pj[u].w);
+            accel_pair<false>(k, s, pi.x - pj[u].x, pi.y - pj[u].y, pi.z - pj[u].z, dj[u], pj[u].w,
+                              vj[u].x, vj[u].y, vj[u].z, bc.x, bc.y);
+         }
+      }
    }
    acc[i] = accel_end<false>(k, s);
 }
