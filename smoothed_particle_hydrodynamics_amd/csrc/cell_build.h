@@ -252,7 +252,14 @@ k_rank_order(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key
    const uint32_t c = key[i];
    const uint32_t s = cell_start[c], e = cell_start[c + 1];
    uint32_t rank = 0;
-   for (uint32_t q = s; q < e; q++) rank += (perm[q] < i) ? 1u : 0u;
+   // eight cell members per trip (independent loads; positions past the end re-read the last)
+   for (uint32_t q0 = s; q0 < e; q0 += 8) {
+      uint32_t other[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) other[u] = perm[q0 + u < e ? q0 + u : e - 1];
+#pragma unroll
+      for (int u = 0; u < 8; u++) rank += (q0 + u < e && other[u] < i) ? 1u : 0u;
+   }
    order[s + rank] = i;
 }
 
