@@ -626,44 +626,36 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       const int pp = p0 + tid;
       if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
    }
+   if (tid <= NLIST_CAP) L.hist[tid] = 0;   // (the descriptor load's barrier covers this too)
    tile_desc_load(desc, wg, L.desc);
    const int total = L.desc.total;
    if (total > tile_cap) return;  // does not fit this pass's wider entries: on the give-up list
-   {
-      int B[9], D[9];
+   int B[9], D[9];
 #pragma unroll
-      for (int kk = 0; kk < 9; kk++) {
-         B[kk] = L.desc.B[kk];
-         D[kk] = L.desc.D[kk];
-      }
-      for (int base = 0; base < total; base += TILE_BATCH * TILE_THREADS) {
-         // unconditional loads, index clamped into the tile (see tile_load)
-         float4 buf[TILE_BATCH];
-         float cbuf[TILE_BATCH];
-#pragma unroll
-         for (int r = 0; r < TILE_BATCH; r++) {
-            const int idx = min(base + tid + r * TILE_THREADS, total - 1);
-            int d = D[0];
-#pragma unroll
-            for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
-            buf[r] = posm[idx - d];
-            cbuf[r] = auxc[idx - d];
-         }
-#pragma unroll
-         for (int r = 0; r < TILE_BATCH; r++) {
-            const int idx = base + tid + r * TILE_THREADS;
-            if (idx < total) xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
-         }
-      }
+   for (int kk = 0; kk < 9; kk++) {
+      B[kk] = L.desc.B[kk];
+      D[kk] = L.desc.D[kk];
    }
-   __syncthreads();
+   // Prologue order: the first batch of tile loads is issued, then - while it is in flight - the
+   // lanes are dealt their particles, whose own loads and first list words go out next; only then
+   // are the tile's entries stored to LDS.  Unconditional loads, index clamped into the tile (see
+   // tile_load).
+   float4 buf[TILE_BATCH];
+   float cbuf[TILE_BATCH];
+#pragma unroll
+   for (int r = 0; r < TILE_BATCH; r++) {
+      const int idx = min(tid + r * TILE_THREADS, total - 1);
+      int d = D[0];
+#pragma unroll
+      for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
+      buf[r] = posm[idx - d];
+      cbuf[r] = auxc[idx - d];
+   }
 
    // Lane <-> particle assignment: the loop below runs to the largest neighbour count in the
    // wave, so lanes are handed particles in order of their count (counting sort through LDS):
    // every wave then works on particles with nearly equal counts.  Each lane's sum is
    // independent, so the assignment does not change any result.
-   if (tid <= NLIST_CAP) L.hist[tid] = 0;
-   __syncthreads();
    const int slot = atomicAdd(&L.hist[my_cnt], 1);
    __syncthreads();
    if (tid < SPH_WAVE) {
@@ -696,6 +688,31 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       rho_i = rho[p];
       cnt = ncount[p];
    }
+
+   // the tile: first batch from the registers, then whatever is left
+#pragma unroll
+   for (int r = 0; r < TILE_BATCH; r++) {
+      const int idx = tid + r * TILE_THREADS;
+      if (idx < total) xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
+   }
+   for (int base = TILE_BATCH * TILE_THREADS; base < total; base += TILE_BATCH * TILE_THREADS) {
+#pragma unroll
+      for (int r = 0; r < TILE_BATCH; r++) {
+         const int idx = min(base + tid + r * TILE_THREADS, total - 1);
+         int d = D[0];
+#pragma unroll
+         for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
+         buf[r] = posm[idx - d];
+         cbuf[r] = auxc[idx - d];
+      }
+#pragma unroll
+      for (int r = 0; r < TILE_BATCH; r++) {
+         const int idx = base + tid + r * TILE_THREADS;
+         if (idx < total) xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
+      }
+   }
+   __syncthreads();
+
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
    // every listed pair passed the exact d2 < h2 test: the division's range checks are uniform
