@@ -205,10 +205,14 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, scaling, steps, w
     slab.upload(mine.astype(np.uint32), scenes.box_fill_subset(mine, (0.0, 0.0, 0.0), hi),
                 np.zeros(3 * mine.size, np.float32), np.ones(mine.size, np.float32),
                 all_masses_equal=True)
-    # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P)
-    host = os.environ.get("SPH_SLAB_TRANSPORT") == "host"
-    transport = (SL.HostStagedTransport if host else SL.DistTransport)(rank, world)
-    stepper = SL.DistSlabStepper(slab, transport)
+    # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P);
+    # =native lets libsph_hip.so issue the RCCL calls itself (no Python in the step loop)
+    mode = os.environ.get("SPH_SLAB_TRANSPORT", "torch")
+    if mode == "native":
+        stepper = SL.NativeSlabStepper(slab, rank, world)
+    else:
+        transport = (SL.HostStagedTransport if mode == "host" else SL.DistTransport)(rank, world)
+        stepper = SL.DistSlabStepper(slab, transport)
 
     def fence():
         slab.synchronize()
@@ -245,7 +249,9 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, scaling, steps, w
     slab.close()
     return {"params": p, "dt": dt, "totals": totals, "covered": covered, "n": n,
             "n_rank": st["owned"], "neighbors_mean": nb_mean, "steps": steps, "box": box,
-            "parallelism": "z-slab x%d, RCCL halo" % world}
+            "parallelism": "z-slab x%d, RCCL halo (%s)" % (
+                world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so",
+                        "host": "host-staged rehearsal"}.get(mode, "torch.distributed P2P"))}
 
 
 def main():
@@ -274,7 +280,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("SPH_SLAB_TRANSPORT") == "host":
+        if (os.environ.get("SPH_SLAB_TRANSPORT") == "host" or
+                os.environ.get("SPH_BENCH_ONE_DEVICE") == "1"):   # rehearsals: ranks share a GPU
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,

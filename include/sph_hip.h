@@ -254,6 +254,21 @@ int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const voi
 int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right_device,
                             int capacity_records, void* exchange_stream);
 int sph_hip_slab_step_end(sph_hip_context* ctx);
+/* ---- native RCCL exchange (no Python, no torch) ----
+ * librccl is opened with dlopen on first use.  One rank (any) calls sph_hip_rccl_unique_id and
+ * hands the 128 bytes to every rank (MPI, a file, a socket, torch.distributed ...); every rank
+ * then calls sph_hip_slab_comm_init on its slab context - ranks are ordered along z, rank r's
+ * neighbours are r - 1 and r + 1 - which creates the communicator, a high-priority exchange
+ * stream and the four message buffers (capacity_records must be the same on all ranks).
+ * sph_hip_slab_comm_run(steps) is then the whole loop: a first serial exchange, and per step
+ * sph_hip_slab_step_begin -> ncclSend/ncclRecv of both directions in one group on the exchange
+ * stream -> sph_hip_slab_step_end -> sph_hip_slab_unpack.  Asynchronous like sph_hip_run.
+ * sph_hip_slab_comm_selftest sends a message to itself through the same calls (synchronises). */
+int sph_hip_rccl_unique_id(void* id_out, int id_bytes);
+int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, int rank, int nranks,
+                           int capacity_records);
+int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps);
+int sph_hip_slab_comm_selftest(sph_hip_context* ctx);
 /* Diagnostics (synchronises): live entries, owned particles, error bits (1: a received entry
  * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded,
  * 8: a particle missed the early exchange). */

@@ -10,13 +10,14 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["sph_hip.hip"]
-HEADERS = ["sph_device.h", "cell_build.h", "pair_math.h", "full_kernels.h", "ref_kernels.h",
-           "common_kernels.h", os.path.join("..", "..", "include", "sph_hip.h")]
+HEADERS = ["sph_device.h", "cell_build.h", "pair_math.h", "full_kernels.h", "full_tiled.h",
+           "ref_kernels.h", "common_kernels.h", "slab_kernels.h", "slab_rccl.h",
+           os.path.join("..", "..", "include", "sph_hip.h")]
 
 # -ffp-contract=off: the reference's x86-64 IEEE build has no FMA contraction; neighbour
 # membership (d^2 < h^2) and the order-sensitive viscous sum must round identically.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared", "-Wall"]
+               "-shared", "-Wall", "-ldl"]
 
 
 def library_path():

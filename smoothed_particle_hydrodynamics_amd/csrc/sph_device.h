@@ -151,6 +151,7 @@ struct sph_hip_context {
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
    int may_hold_dead = 0;          // sph_hip_slab_pack has marked entries dead since the last cell build
    int early_exchange = 0;         // the last step packed its messages early (sph_hip_slab_step_begin)
+   struct SlabComm* comm = nullptr;     // native RCCL exchange (csrc/slab_rccl.h), or null
    hipStream_t border_stream = nullptr; // stream the last step_begin put the border work on
    hipEvent_t ev_density = nullptr; // early exchange: density done (main stream) -> border work may start
    hipEvent_t ev_border = nullptr;  //                 border acceleration done (exchange stream) -> integrate may run

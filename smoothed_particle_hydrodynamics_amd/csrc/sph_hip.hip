@@ -13,6 +13,7 @@
 #include "full_tiled.h"
 #include "ref_kernels.h"
 #include "slab_kernels.h"
+#include "slab_rccl.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -88,6 +89,21 @@ void free_all(sph_hip_context* ctx)
       for (int k = 0; k < EV_RING * 7; k++)
          if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
       delete[] ctx->ev;
+   }
+   if (ctx->comm) {
+      SlabComm* c = ctx->comm;
+      if (c->stream) (void)hipStreamSynchronize(c->stream);
+      if (c->comm) {
+         const RcclApi* api = rccl_api(nullptr);
+         if (api) (void)api->CommDestroy(c->comm);
+      }
+      for (void* q : {c->send_left, c->send_right, c->recv_left, c->recv_right})
+         if (q) (void)hipFree(q);
+      if (c->packed) (void)hipEventDestroy(c->packed);
+      if (c->arrived) (void)hipEventDestroy(c->arrived);
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+      delete c;
+      ctx->comm = nullptr;
    }
    if (ctx->ev_density) (void)hipEventDestroy(ctx->ev_density);
    if (ctx->ev_border) (void)hipEventDestroy(ctx->ev_border);
@@ -976,6 +992,176 @@ int sph_hip_slab_step_end(sph_hip_context* ctx)
    if ((rc = launch_integrate(ctx))) return rc;
    if (phases) SPH_TRY(hipEventRecord(ev[6], st));
    if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;
+   return SPH_HIP_OK;
+}
+
+// ---- native RCCL exchange -------------------------------------------------------------------
+
+#define SPH_NCCL_TRY(call)                                                                    \
+   do {                                                                                       \
+      const ncclResult_t r_ = (call);                                                         \
+      if (r_ != ncclSuccess) {                                                                \
+         ctx->err = std::string(#call " failed: ") + api->GetErrorString(r_);                 \
+         return SPH_HIP_ERR_DEVICE;                                                          \
+      }                                                                                       \
+   } while (0)
+
+int sph_hip_rccl_unique_id(void* id_out, int id_bytes)
+{
+   std::string why;
+   const RcclApi* api = rccl_api(&why);
+   if (!api || !id_out || id_bytes < (int)sizeof(ncclUniqueId)) {
+      g_create_error = api ? "sph_hip_rccl_unique_id: buffer too small (128 bytes needed)" : why;
+      return SPH_HIP_ERR_INVALID;
+   }
+   ncclUniqueId id;
+   if (api->GetUniqueId(&id) != ncclSuccess) {
+      g_create_error = "ncclGetUniqueId failed";
+      return SPH_HIP_ERR_DEVICE;
+   }
+   memcpy(id_out, &id, sizeof(id));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, int rank, int nranks,
+                           int capacity_records)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || !id || id_bytes < (int)sizeof(ncclUniqueId) || rank < 0 ||
+       rank >= nranks || capacity_records < 1) {
+      ctx->err = "sph_hip_slab_comm_init: bad arguments";
+      return SPH_HIP_ERR_INVALID;
+   }
+   // slabs are ordered by rank along z: the neighbours of rank r are r - 1 and r + 1
+   if ((rank > 0) != (ctx->plane_lo > 0) || (rank + 1 < nranks) != (ctx->plane_hi < ctx->grid.nz_global)) {
+      ctx->err = "sph_hip_slab_comm_init: the slab's planes do not match its rank (rank 0 owns "
+                 "plane 0, the last rank the last plane)";
+      return SPH_HIP_ERR_INVALID;
+   }
+   if (ctx->comm) {
+      ctx->err = "sph_hip_slab_comm_init: already initialised";
+      return SPH_HIP_ERR_INVALID;
+   }
+   std::string why;
+   const RcclApi* api = rccl_api(&why);
+   if (!api) {
+      ctx->err = why;
+      return SPH_HIP_ERR_DEVICE;
+   }
+   SPH_TRY(hipSetDevice(ctx->device));
+   SlabComm* c = new (std::nothrow) SlabComm();
+   if (!c) return SPH_HIP_ERR_DEVICE;
+   ctx->comm = c;   // from here on sph_hip_destroy cleans up
+   c->rank = rank;
+   c->nranks = nranks;
+   c->capacity_records = capacity_records;
+   c->bytes = sph_hip_slab_message_bytes(capacity_records);
+   int least = 0, greatest = 0;
+   SPH_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+   SPH_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+   SPH_TRY(hipEventCreateWithFlags(&c->packed, hipEventDisableTiming));
+   SPH_TRY(hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming));
+   void** bufs[4] = {&c->send_left, &c->recv_left, &c->send_right, &c->recv_right};
+   for (int b = 0; b < 4; b++) {
+      if (b < 2 ? rank == 0 : rank + 1 == nranks) continue;   // no neighbour on that side
+      SPH_TRY(hipMalloc(bufs[b], c->bytes));
+      SPH_TRY(hipMemsetAsync(*bufs[b], 0, c->bytes, ctx->stream));
+   }
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   ncclUniqueId uid;
+   memcpy(&uid, id, sizeof(uid));
+   SPH_NCCL_TRY(api->CommInitRank(&c->comm, nranks, uid, rank));
+   return SPH_HIP_OK;
+}
+
+namespace {
+// both directions in one group on the exchange stream
+int comm_send_recv(sph_hip_context* ctx)
+{
+   SlabComm* c = ctx->comm;
+   const RcclApi* api = rccl_api(nullptr);
+   if (c->rank == 0 && c->rank + 1 == c->nranks) return SPH_HIP_OK;
+   SPH_NCCL_TRY(api->GroupStart());
+   if (c->rank > 0) {
+      SPH_NCCL_TRY(api->Send(c->send_left, c->bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+      SPH_NCCL_TRY(api->Recv(c->recv_left, c->bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+   }
+   if (c->rank + 1 < c->nranks) {
+      SPH_NCCL_TRY(api->Send(c->send_right, c->bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+      SPH_NCCL_TRY(api->Recv(c->recv_right, c->bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+   }
+   SPH_NCCL_TRY(api->GroupEnd());
+   return SPH_HIP_OK;
+}
+} // namespace
+
+int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SlabComm* c = ctx->comm;
+   if (!c || !c->comm || steps < 0) {
+      ctx->err = "sph_hip_slab_comm_run: sph_hip_slab_comm_init first";
+      return SPH_HIP_ERR_INVALID;
+   }
+   hipStream_t st = ctx->stream;
+   if (!c->primed) {
+      // the first ghosts: pack -> send/recv -> unpack, serially
+      if ((rc = sph_hip_slab_pack(ctx, c->send_left, c->send_right, c->capacity_records))) return rc;
+      SPH_TRY(hipEventRecord(c->packed, st));
+      SPH_TRY(hipStreamWaitEvent(c->stream, c->packed, 0));
+      if ((rc = comm_send_recv(ctx))) return rc;
+      SPH_TRY(hipEventRecord(c->arrived, c->stream));
+      SPH_TRY(hipStreamWaitEvent(st, c->arrived, 0));
+      if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->capacity_records))) return rc;
+      c->primed = true;
+   }
+   for (int s = 0; s < steps; s++) {
+      // border planes + messages on the exchange stream, transfer behind them; the interior's
+      // acceleration and the integrate meanwhile on the context's stream
+      if ((rc = sph_hip_slab_step_begin(ctx, c->send_left, c->send_right, c->capacity_records, c->stream)))
+         return rc;
+      if ((rc = comm_send_recv(ctx))) return rc;
+      SPH_TRY(hipEventRecord(c->arrived, c->stream));
+      if ((rc = sph_hip_slab_step_end(ctx))) return rc;
+      SPH_TRY(hipStreamWaitEvent(st, c->arrived, 0));
+      if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->capacity_records))) return rc;
+   }
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_comm_selftest(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SlabComm* c = ctx->comm;
+   if (!c || !c->comm) {
+      ctx->err = "sph_hip_slab_comm_selftest: sph_hip_slab_comm_init first";
+      return SPH_HIP_ERR_INVALID;
+   }
+   const RcclApi* api = rccl_api(nullptr);
+   // a message to oneself through the same calls, stream and group shape the exchange uses
+   const size_t n = 1 << 20;
+   unsigned char *a = nullptr, *b = nullptr;
+   SPH_TRY(hipMalloc((void**)&a, n));
+   SPH_TRY(hipMalloc((void**)&b, n));
+   std::string host(n, '\0'), back(n, '\0');
+   for (size_t i = 0; i < n; i++) host[i] = (char)((i * 2654435761u) >> 13);
+   SPH_TRY(hipMemcpy(a, host.data(), n, hipMemcpyHostToDevice));
+   SPH_TRY(hipMemset(b, 0, n));
+   SPH_NCCL_TRY(api->GroupStart());
+   SPH_NCCL_TRY(api->Send(a, n, ncclChar, c->rank, c->comm, c->stream));
+   SPH_NCCL_TRY(api->Recv(b, n, ncclChar, c->rank, c->comm, c->stream));
+   SPH_NCCL_TRY(api->GroupEnd());
+   SPH_TRY(hipStreamSynchronize(c->stream));
+   SPH_TRY(hipMemcpy(&back[0], b, n, hipMemcpyDeviceToHost));
+   (void)hipFree(a);
+   (void)hipFree(b);
+   if (back != host) {
+      ctx->err = "sph_hip_slab_comm_selftest: the message came back different";
+      return SPH_HIP_ERR_DEVICE;
+   }
    return SPH_HIP_OK;
 }
 

@@ -93,6 +93,10 @@ PROTOTYPES = {
     "sph_hip_slab_unpack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
     "sph_hip_slab_step_begin": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sph_hip_slab_step_end": (C.c_int, [_ctx]),
+    "sph_hip_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
+    "sph_hip_slab_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sph_hip_slab_comm_run": (C.c_int, [_ctx, C.c_int]),
+    "sph_hip_slab_comm_selftest": (C.c_int, [_ctx]),
     "sph_hip_slab_status": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
 }
 

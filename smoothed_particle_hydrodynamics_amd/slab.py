@@ -160,6 +160,22 @@ class HipSlab:
         """Acceleration of the interior, integrate (sph_hip_slab_step_end)."""
         self._check(self._lib.sph_hip_slab_step_end(self._ctx), "sph_hip_slab_step_end")
 
+    # ---- native RCCL exchange (the library issues ncclSend/ncclRecv itself) ----------------------
+    def comm_init(self, unique_id, rank, world):
+        """Create this slab's RCCL communicator from the 128-byte id every rank shares
+        (rccl_unique_id() on one rank, then any broadcast)."""
+        buf = (C.c_char * len(unique_id)).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.sph_hip_slab_comm_init(self._ctx, buf, len(unique_id), int(rank),
+                                                     int(world), self.msg_capacity),
+                    "sph_hip_slab_comm_init")
+
+    def comm_run(self, steps):
+        """`steps` steps with the overlapped neighbour exchange, all enqueued by the library."""
+        self._check(self._lib.sph_hip_slab_comm_run(self._ctx, int(steps)), "sph_hip_slab_comm_run")
+
+    def comm_selftest(self):
+        self._check(self._lib.sph_hip_slab_comm_selftest(self._ctx), "sph_hip_slab_comm_selftest")
+
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
 
@@ -230,6 +246,36 @@ def slab_capacities(counts_per_plane, cuts, rank, slack=1.5):
                     counts_per_plane[c:min(c + HALO, nz)].sum())
     msg = int(strip * slack * 1.5) + 4096
     return cap, msg
+
+
+def rccl_unique_id():
+    """128 bytes naming a new RCCL communicator (call on ONE rank, broadcast to the others)."""
+    lib = load_library()
+    buf = (C.c_char * 128)()
+    rc = lib.sph_hip_rccl_unique_id(buf, 128)
+    if rc != 0:
+        raise SphHipError("sph_hip_rccl_unique_id failed (%d): %s" %
+                          (rc, lib.sph_hip_last_error(None).decode()))
+    return bytes(buf)
+
+
+class NativeSlabStepper:
+    """The per-rank loop with the exchange issued by libsph_hip.so itself (RCCL through dlopen):
+    torch.distributed is used once, to hand rank 0's communicator id to everybody."""
+
+    def __init__(self, slab, rank, world, group=None):
+        import torch.distributed as dist
+        ident = [rccl_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        slab.comm_init(ident[0], rank, world)
+        self.slab = slab
+
+    def step(self):
+        self.slab.comm_run(1)
+
+    def run(self, steps):
+        self.slab.comm_run(steps)
 
 
 class DistTransport:

@@ -181,3 +181,29 @@ def test_random_slab_runs_equal_single_context(hiplib, case):
     assert np.array_equal(got["acc"], part.mAcceleration), what + "acceleration"
     assert np.array_equal(got["pos"], part.mPosition), what + "position"
     assert np.array_equal(got["vel"], part.mVelocity), what + "velocity"
+
+
+def test_native_rccl_exchange_single_rank(oracle, hiplib):
+    """The library's own RCCL path as far as one GPU can take it: librccl opened with dlopen, a
+    1-rank communicator, a message sent to itself through the same grouped ncclSend/ncclRecv on
+    the exchange stream (selftest), and sph_hip_slab_comm_run on a slab that holds the whole grid
+    (no neighbours: every launch of the overlapped step, no transfer) against the oracle."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    p, pos, vel, mass = moving_block(20000, unequal=True)
+    s = SL.HipSlab(p, 0, p.full_cells_z, 40000, 4096, device=0, has_left=False, has_right=False)
+    s.upload(np.arange(mass.size, dtype=np.uint32), pos, vel, mass, all_masses_equal=False)
+    s.comm_init(SL.rccl_unique_id(), 0, 1)
+    s.comm_selftest()
+    s.comm_run(3)
+    d = s.download()
+    assert s.status()["errors"] == 0
+    opos, ovel = pos.copy(), vel.copy()
+    for _ in range(3):
+        ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+    ids = d["ids"].astype(np.int64)
+    assert np.array_equal(np.sort(ids), np.arange(mass.size))
+    assert np.array_equal(d["pos"].reshape(-1, 3), opos.reshape(-1, 3)[ids])
+    assert np.array_equal(d["acc"].reshape(-1, 3), ref["acc"].reshape(-1, 3)[ids])
+    assert np.array_equal(d["rho"], ref["rho"][ids])
+    s.close()
