@@ -36,7 +36,9 @@
 #define ACCEL_TILE_BYTES 16
 // launch bounds = the most workgroups per CU the register budget should allow
 #define DENSITY_BLOCKS (6 * 256 / TILE_THREADS)
+#ifndef ACCEL_BLOCKS
 #define ACCEL_BLOCKS (TILE_THREADS == 256 ? 5 : 2)
+#endif
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
 // NLIST_WORDS rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
 // reads/writes 256 contiguous bytes).  Only rows in use are ever touched.

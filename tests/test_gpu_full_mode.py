@@ -266,3 +266,33 @@ print("confirmed")
     env = dict(os.environ, SPH_HIP_TEST_SCREEN="1.05")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "confirmed" in out.stdout, out.stdout + out.stderr
+
+
+def test_full_long_run_adaptive_capacity_equals_fixed(hiplib, monkeypatch):
+    """A dam that actually breaks (gravity + walls on, 400 steps): the column collapses, tile sizes
+    and the capacity levels picked from the feedback change along the way.  The run must end in
+    exactly the state of a run with the capacity pinned, and stay finite."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(150000)
+    p.apply_gravity = 1
+    p.apply_walls = 1
+    p.gravity[0], p.gravity[1], p.gravity[2] = 0.0, -9.81, 0.0
+    out = []
+    for cap in (None, "3008"):
+        if cap is None:
+            monkeypatch.delenv("SPH_HIP_TILE_CAP", raising=False)
+        else:
+            monkeypatch.setenv("SPH_HIP_TILE_CAP", cap)
+        with S.SPH(mass.size, p) as sph:
+            sph.setParticles(pos, vel, mass)
+            sph.run(400)
+            part = sph.getParticles()
+            ke, pe = sph.energy()
+            assert np.isfinite(ke) and np.isfinite(part.mPosition).all()
+            out.append([getattr(part, nm).copy() for nm in
+                        ("mPosition", "mVelocity", "mDensity", "mAcceleration", "mNeighborCount")])
+    moved = np.abs(out[0][0] - pos).max()
+    assert moved > 0.01, "the column is meant to move (moved %g)" % moved
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
