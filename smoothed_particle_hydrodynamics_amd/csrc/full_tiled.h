@@ -42,10 +42,14 @@
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
 // NLIST_WORDS rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
 // reads/writes 256 contiguous bytes).  Only rows in use are ever touched.
-#define NLIST_CAP 96
+#ifndef NLIST_CAP
+#define NLIST_CAP 254   // neighbours per particle the lists hold (a breaking dam compresses to > 100)
+#endif
 // two entries per 32-bit word: word r of a lane holds its entries 2r (low half) and 2r+1;
 // one spare word row swallows overflowing appends
 #define NLIST_WORDS (NLIST_CAP / 2 + 1)
+// bins of the neighbour-count histogram one lane of the scanning wave handles
+#define HIST_PER_LANE ((NLIST_CAP + 1 + SPH_WAVE - 1) / SPH_WAVE)
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
 #ifndef DENSITY_UNROLL
 #define DENSITY_UNROLL 6
@@ -555,10 +559,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // single neighbours up, so one ds_read_b128 per neighbour beats four scattered ds_read_b32.
 struct AccelLds {
    TileDesc desc;
-   int hist[2 * SPH_WAVE];         // neighbour-count histogram / its exclusive scan (NLIST_CAP+1 used)
+   int hist[HIST_PER_LANE * SPH_WAVE];  // neighbour-count histogram / its exclusive scan (NLIST_CAP+1 used)
    uint16_t perm[TILE_THREADS];    // lane -> list column, ascending neighbour count
 };
-static_assert(NLIST_CAP + 1 <= 2 * SPH_WAVE, "count histogram is scanned by one wave, two entries per lane");
+static_assert(NLIST_CAP + 1 <= TILE_THREADS, "the histogram is cleared by one thread per bin");
 
 // The acceleration pass can be launched in two parts (early exchange): part 1 = the workgroups
 // that hold a particle of the owned planes next to a neighbouring slab (sorted ranges
@@ -661,17 +665,26 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int slot = atomicAdd(&L.hist[my_cnt], 1);
    __syncthreads();
    if (tid < SPH_WAVE) {
-      // exclusive scan of hist[0..NLIST_CAP] by one wave (two entries per lane)
-      const int a = L.hist[2 * tid], b = (2 * tid + 1 <= NLIST_CAP) ? L.hist[2 * tid + 1] : 0;
-      int inc = a + b;
+      // exclusive scan of hist[0..NLIST_CAP] by one wave (HIST_PER_LANE consecutive bins per lane)
+      int bin[HIST_PER_LANE];
+      int sum = 0;
+#pragma unroll
+      for (int u = 0; u < HIST_PER_LANE; u++) {
+         bin[u] = (HIST_PER_LANE * tid + u <= NLIST_CAP) ? L.hist[HIST_PER_LANE * tid + u] : 0;
+         sum += bin[u];
+      }
+      int inc = sum;
 #pragma unroll
       for (int dd = 1; dd < SPH_WAVE; dd <<= 1) {
          const int o = __shfl_up(inc, dd);
          if (tid >= dd) inc += o;
       }
-      const int ex = inc - (a + b);
-      L.hist[2 * tid] = ex;
-      if (2 * tid + 1 <= NLIST_CAP) L.hist[2 * tid + 1] = ex + a;
+      int ex = inc - sum;
+#pragma unroll
+      for (int u = 0; u < HIST_PER_LANE; u++) {
+         if (HIST_PER_LANE * tid + u <= NLIST_CAP) L.hist[HIST_PER_LANE * tid + u] = ex;
+         ex += bin[u];
+      }
    }
    __syncthreads();
    L.perm[L.hist[my_cnt] + slot] = (uint16_t)tid;
