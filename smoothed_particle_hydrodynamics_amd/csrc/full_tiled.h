@@ -48,6 +48,9 @@
 // two entries per 32-bit word: word r of a lane holds its entries 2r (low half) and 2r+1;
 // one spare word row swallows overflowing appends
 #define NLIST_WORDS (NLIST_CAP / 2 + 1)
+// first list word of a particle that has no list (more neighbours than NLIST_CAP): no valid
+// entry has segment id 15
+#define NLIST_NO_LIST 0xffffffffu
 // bins of the neighbour-count histogram one lane of the scanning wave handles
 #define HIST_PER_LANE ((NLIST_CAP + 1 + SPH_WAVE - 1) / SPH_WAVE)
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
@@ -443,16 +446,19 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    }
    if ((count & 1) && count < NLIST_CAP)
       list_block[((uint32_t)count >> 1) * TILE_THREADS + (uint32_t)tid] = hold;
-   if (count > NLIST_CAP) list_overflow = 1;
+   // A particle with more neighbours than its list holds (a scene many times denser than the
+   // benchmark's) goes without a list: its lane walks its candidate ranges in the tile one by one
+   // here - canonical order, small code - and again in the acceleration pass, which recognises it
+   // by the marker in the list's first word; the other lanes of the workgroup keep their lists.
+   const bool overflowed = count > NLIST_CAP;
+   if (overflowed) {
+      list_overflow = 1;
+      list_block[tid] = NLIST_NO_LIST;
+   }
    __syncthreads();
-   const int give_up = list_overflow;
-   if (tid == 0) nlist_overflow[wg] = give_up ? 2u : 0u;
+   if (tid == 0) nlist_overflow[wg] = list_overflow ? 2u : 0u;
    float density = 0.0f;
-   if (give_up) {
-      // Some particle of the workgroup has more than NLIST_CAP neighbours (a scene several times
-      // denser than the lists are sized for): no lists.  Every lane walks its candidate ranges
-      // in the tile one by one - canonical order, small code; the acceleration pass computes the
-      // workgroup untiled.  (A separate fallback launch would cost every step ~55 us.)
+   if (__any(overflowed) && overflowed) {
       count = 0;
       RowRanges rr;   // looked up again rather than kept alive through TEST in every workgroup
 #pragma unroll
@@ -484,10 +490,11 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    // SUM: one pass over the list, in canonical order
    const uint32_t* sum_list = list_block + tid;
    bool screened_wrongly = false;
-   for (int j0 = 0; !give_up && __any(j0 < count); j0 += DENSITY_UNROLL) {
+   const int listed = overflowed ? 0 : count;   // entries to sum from the list
+   for (int j0 = 0; __any(j0 < listed); j0 += DENSITY_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
       uint32_t entry[DENSITY_UNROLL];
-      const int lastw = count > 0 ? (count - 1) >> 1 : 0;
+      const int lastw = listed > 0 ? (listed - 1) >> 1 : 0;
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u += 2) {
          const int w = ((j0 + u) >> 1) < lastw ? ((j0 + u) >> 1) : lastw;
@@ -497,7 +504,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       }
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u++) {
-         if (j0 + u < count) {
+         if (j0 + u < listed) {
             const int t = (int)(entry[u] & QUEUE_TMASK);
             float mj = pi.w;
             if (!UNIFORM_MASS) mj = posm[t - sd.D[entry[u] >> QUEUE_TBITS]].w;
@@ -601,36 +608,23 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // the pass is launched in two parts (early exchange), for those of the other part
    const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&
                     accel_part_has(part, p0, meta);
-   // 1: tile did not fit the density pass (on the give-up list), 2: a neighbour list overflowed
+   // 1: tile did not fit the density pass (on the give-up list), 2: some particle of the
+   // workgroup has no list (more neighbours than NLIST_CAP)
    const uint32_t gave_up = own ? nlist_overflow[wg] : 1u;
-   // Untiled work, one call site: [0] the first workgroups of the launch start with the
-   // workgroups whose tile does not fit (give-up list), so that their long latency overlaps the
-   // rest of the launch; [1] a workgroup whose lists overflowed computes its own particles.
-   {
-      int untiled_p[2] = {-1, -1};
-      const bool listed = (int)blockIdx.x < tile_stats[TSTAT_GIVEUP_ACCEL];
-      if (listed) {
-         const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
-         const int gp = g0 + tid;
-         if (gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta)) untiled_p[0] = gp;
-      }
-      if (gave_up == 2u) {
-         const int pp = p0 + tid;
-         if (pp < end && pp >= ob && pp < oe) untiled_p[1] = pp;
-      }
-#pragma unroll 1
-      for (int u = 0; u < 2; u++) {
-         if (u == 0 ? listed : gave_up == 2u) {  // uniform
-            const int q = u == 0 ? untiled_p[0] : untiled_p[1];
-            if (q >= 0) accel_untiled<UNIT_SCALE>(q, posm, velB, rho, auxc, cell_start, g, k, acc);
-         }
-      }
+   // the first workgroups of the launch start with the workgroups whose tile does not fit
+   // (give-up list), untiled, so that their long latency overlaps the rest of the launch
+   if ((int)blockIdx.x < tile_stats[TSTAT_GIVEUP_ACCEL]) {
+      const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
+      const int gp = g0 + tid;
+      if (gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta))
+         accel_untiled<UNIT_SCALE>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
    }
-   if (gave_up) return;
+   if (gave_up == 1u) return;
    int my_cnt = 0;  // requested before the tile: the lane permutation below needs it
    {
       const int pp = p0 + tid;
-      if (pp < end && pp >= ob && pp < oe) my_cnt = ncount[pp];
+      // (the true count of a particle without a list can exceed the histogram: one bin for all)
+      if (pp < end && pp >= ob && pp < oe) my_cnt = min(ncount[pp], NLIST_CAP);
    }
    if (tid <= NLIST_CAP) L.hist[tid] = 0;   // (the descriptor load's barrier covers this too)
    tile_desc_load(desc, wg, L.desc);
@@ -733,6 +727,11 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // every listed pair passed the exact d2 < h2 test: the division's range checks are uniform
    const bool in_range = accel_operands_in_range(k);
    const uint32_t* my_list = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS) + col;
+   // a particle without a list (marker in its first word; only in workgroups flagged 2): its lane
+   // skips the list loop and walks its candidate ranges in the tile afterwards
+   bool no_list = false;
+   if (gave_up == 2u && cnt > 0) no_list = my_list[0] == NLIST_NO_LIST;
+   if (no_list) cnt = 0;
    // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
    // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
    // so neither of a neighbour's two dependent memory round trips is waited for in isolation.
@@ -773,6 +772,32 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             if (!UNIT_SCALE) d *= k.sim_scale;
             accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
                                    pj.w, in_range);
+         }
+      }
+   }
+   if (gave_up == 2u && __any(no_list) && no_list) {
+      // canonical order: the 9 rows ascending, positions ascending inside a row
+      RowRanges rr;
+      int cx, cy, cz;
+      cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
+      row_ranges(g, cell_start, cx, cy, cz, rr);
+      const int self_t = p + L.desc.D[4];
+#pragma unroll
+      for (int kk = 0; kk < 9; kk++) {
+         const int D = L.desc.D[kk];
+         const int te = (int)rr.e[kk] + D;
+         for (int t = (int)rr.s[kk] + D; t < te; t++) {
+            const float4 pj = xyzc[t];
+            float dx, dy, dz;
+            const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
+            if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
+               float d = sqrtf(d2);
+               if (!UNIT_SCALE) d *= k.sim_scale;
+               const float4 vj = velB[t - D];
+               float mj = pi.w;
+               if (!UNIFORM_MASS) mj = posm[t - D].w;
+               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, vj.w, pj.w, in_range);
+            }
          }
       }
    }
