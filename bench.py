@@ -29,8 +29,10 @@ DENSITY_FORCE_BYTES = 64       # algorithmic bytes per particle of the density+f
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps first (the first ~5 steps after an upload run 5-10 %% "
+                         "slower than the steady state)")
     ap.add_argument("--particles", type=int, default=4 * 1024 * 1024,
                     help="particles of the 1-GPU workload (default: BASELINE config C3, 4M)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",

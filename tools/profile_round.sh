@@ -11,7 +11,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py > $out/${tag}_bench.json
 cat $out/${tag}_bench.json
-args="bench.py --steps 20 --warmup 3 --cpu-sample 0"
+args="bench.py --steps 20 --warmup 5 --cpu-sample 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python3 $args > $out/${tag}_stats.log 2>&1
 pargs="bench.py --steps 4 --warmup 1 --cpu-sample 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python3 $pargs > $out/${tag}_pmc_fetch.log 2>&1
