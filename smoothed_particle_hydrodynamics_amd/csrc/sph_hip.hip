@@ -633,7 +633,10 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(dev_alloc(&ctx->velB, cap));
       CREATE_TRY(dev_alloc(&ctx->auxc, cap));
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
-      CREATE_TRY(dev_alloc(&ctx->nlist, ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS));
+      const size_t nlist_words = ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS;
+      CREATE_TRY(dev_alloc(&ctx->nlist, nlist_words));
+      // touched once here, so that the first step does not pay for mapping the pages
+      CREATE_TRY(hipMemsetAsync(ctx->nlist, 0, nlist_words * sizeof(uint32_t), ctx->stream));
       CREATE_TRY(dev_alloc(&ctx->nlist_overflow, (size_t)div_up(capacity, TILE_THREADS) + 1));
       if (const char* v = getenv("SPH_HIP_UNTILED")) ctx->use_tiled = (v[0] == '1') ? 0 : 1;
       CREATE_TRY(hipHostMalloc((void**)&ctx->tile_feedback, TSTAT_COUNT * sizeof(int), hipHostMallocDefault));
