@@ -174,6 +174,14 @@ int sph_hip_reset_timings(sph_hip_context* ctx);
 #define SPH_HIP_TIMING_PHASES 2
 int sph_hip_set_timing(sph_hip_context* ctx, int level);
 
+/* FULL mode, tiled kernels: statistics of the LDS tiles of the last step (synchronises).
+ * out[0..11]: workgroups whose tile exceeds capacity level i (the levels are the largest tiles
+ * that allow a given number of workgroups per CU), out[12]: workgroups, out[13]: largest tile
+ * (entries), out[14], out[15]: workgroups computed untiled in the density / acceleration pass,
+ * out[16], out[17]: tile capacities the two passes were launched with, out[18]: 1 if the list
+ * entries were in their wide format (a capacity above 4064), out[19]: 0. */
+int sph_hip_get_tile_stats(sph_hip_context* ctx, int32_t out[20]);
+
 /* mKineticEnergyTotal / mPotentialEnergyTotal of the last integrate
  * (reference src/sph.cpp:1001-1013).  Summed in double in a fixed tree order; the
  * reference's serial fp32 sum is order-dependent, so compare with a tolerance. */

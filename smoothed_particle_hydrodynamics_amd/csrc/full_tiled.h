@@ -30,7 +30,8 @@
 // workgroups a CU can hold (and with them the latency hiding of both passes) is set by the LDS
 // a workgroup asks for: 12 B (density) / 16 B (acceleration) per tile entry.
 #define TILE_PAD 32                      // slots past the capacity that aligned 8-slot reads may touch
-#define TILE_CAP_MAX (4096 - TILE_PAD)   // tile indices are 12-bit in the list entries
+#define TILE_CAP_MAX (4096 - TILE_PAD)        // tile indices are 12-bit in narrow list entries
+#define TILE_CAP_MAX_WIDE (16384 - TILE_PAD)  // ... 14-bit in wide ones
 #define TILE_BATCH 8                     // 16-byte loads a thread keeps in flight while filling the tile
 #define DENSITY_TILE_BYTES 12
 #define ACCEL_TILE_BYTES 16
@@ -63,9 +64,32 @@
 #ifndef ACCEL_UNROLL
 #define ACCEL_UNROLL 8
 #endif
-// queue entry: segment id << 12 | tile index (TILE_CAP + 32 <= 4096)
-#define QUEUE_TBITS 12
-#define QUEUE_TMASK 0xfffu
+// A 16-bit list entry is a tile index plus what it takes to get back from it to the neighbour's
+// sorted position (tile index - D[segment]).  Narrow (tiles up to 4064 entries): segment id << 12 |
+// 12-bit index.  Wide (scenes several times denser, tiles up to 16352 entries, chosen per step by
+// the host): plane dz + 1 << 14 | 14-bit index; the row inside the plane follows from the index
+// and the descriptor's segment starts B - two more LDS reads and compares per neighbour, which is
+// why it is not the only format.
+template <bool WIDE>
+struct ListEntry {
+   static constexpr int TBITS = WIDE ? 14 : 12;
+   static constexpr uint32_t TMASK = (1u << TBITS) - 1u;
+   __device__ static __forceinline__ uint32_t tag(int segment)
+   {
+      return (uint32_t)(WIDE ? segment / 3 : segment) << TBITS;
+   }
+   __device__ static __forceinline__ int tile(uint32_t e) { return (int)(e & TMASK); }
+   // D of the entry's segment.  Segments of a plane that share storage have equal D, and an
+   // empty segment starts where the next begins, so comparing with the starts finds a valid one.
+   template <class Desc>
+   __device__ static __forceinline__ int shift(const Desc& d, uint32_t e)
+   {
+      if (!WIDE) return d.D[e >> TBITS];
+      const int z = (int)(e >> TBITS), t = (int)(e & TMASK);
+      const int k = 3 * z + (t >= d.B[3 * z + 1] ? 1 : 0) + (t >= d.B[3 * z + 2] ? 1 : 0);
+      return d.D[k];
+   }
+};
 
 typedef float __attribute__((ext_vector_type(2))) f32x2;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
@@ -77,7 +101,9 @@ __device__ __forceinline__ f32x4 lds_read4(const float* base, int i)
 }
 
 static_assert(DENSITY_UNROLL % 2 == 0 && ACCEL_UNROLL % 2 == 0 && NLIST_CAP % 2 == 0, "entries travel in pairs");
-static_assert(TILE_CAP_MAX + TILE_PAD <= (1 << QUEUE_TBITS), "tile index must fit the list entry");
+static_assert(TILE_CAP_MAX + TILE_PAD <= (1 << ListEntry<false>::TBITS) &&
+                 TILE_CAP_MAX_WIDE + TILE_PAD <= (1 << ListEntry<true>::TBITS),
+              "tile index must fit the list entry");
 
 // Per-workgroup tile layout, computed by k_tile_desc before the sums run.
 struct TileDesc {
@@ -318,7 +344,7 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
 // column of the workgroup's list block in global memory; SUM then walks that list once.  The
 // list doubles as the input of the acceleration pass.  A workgroup in which some particle has
 // more than NLIST_CAP neighbours gives up (flag) and runs the untiled code inline instead.
-template <bool UNIT_SCALE, bool UNIFORM_MASS>
+template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE>
 __global__ void __launch_bounds__(TILE_THREADS, DENSITY_BLOCKS)
 k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
                      const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
@@ -389,7 +415,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = sd.D[kk];
-      const uint32_t kbits = (uint32_t)kk << QUEUE_TBITS;
+      const uint32_t kbits = ListEntry<WIDE>::tag(kk);
       const int ts = (int)r.s[kk] + D;
       const int te = (int)r.e[kk] + D;
       // chunks of 32 tile slots starting at an 8-aligned slot; one acceptance bit per slot
@@ -505,9 +531,9 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u++) {
          if (j0 + u < listed) {
-            const int t = (int)(entry[u] & QUEUE_TMASK);
+            const int t = ListEntry<WIDE>::tile(entry[u]);
             float mj = pi.w;
-            if (!UNIFORM_MASS) mj = posm[t - sd.D[entry[u] >> QUEUE_TBITS]].w;
+            if (!UNIFORM_MASS) mj = posm[t - ListEntry<WIDE>::shift(sd, entry[u])].w;
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
             if (d2 < k.h2) {             // the reference's own test, on the reference's own value
@@ -533,7 +559,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             for (int half = 0; half < 2; half++) {
                if (j + half < count) {
                   const uint32_t entry = half ? word >> 16 : word & 0xffffu;
-                  const int t = (int)(entry & QUEUE_TMASK);
+                  const int t = ListEntry<WIDE>::tile(entry);
                   float dx, dy, dz;
                   if (dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz) < k.h2) {
                      if (kept & 1) list_block[((uint32_t)kept >> 1) * TILE_THREADS + (uint32_t)tid] = out_hold | (entry << 16);
@@ -585,7 +611,7 @@ __device__ __forceinline__ bool accel_part_has(int part, int p0, const int32_t* 
    return border == (part == 1);
 }
 
-template <bool UNIT_SCALE, bool UNIFORM_MASS>
+template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE>
 __global__ void __launch_bounds__(TILE_THREADS, ACCEL_BLOCKS)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
                    const float* __restrict__ rho, const float* __restrict__ auxc,
@@ -746,7 +772,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
-         const int q = (int)(entry[u] & QUEUE_TMASK) - L.desc.D[entry[u] >> QUEUE_TBITS];
+         const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
          const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
 #if defined(SPH_ABLATE) && SPH_ABLATE == 7
          vj[u] = make_float4(1.f, 2.f, 3.f, 4.f);  // timing only: no gather
@@ -765,7 +791,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          if (j0 + u < cnt) {
-            const float4 pj = xyzc[entry[u] & QUEUE_TMASK];
+            const float4 pj = xyzc[ListEntry<WIDE>::tile(entry[u])];
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             float d = sqrtf(d2);

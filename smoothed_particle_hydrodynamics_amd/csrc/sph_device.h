@@ -61,7 +61,7 @@ struct SlabZone {
 
 // Per-step statistics of the LDS tiles (k_tile_desc), fed back to the host's choice of tile
 // capacity: how many workgroups would not fit each candidate capacity.
-#define TILE_CANDS 8
+#define TILE_CANDS 12
 // density pass: widening of h2 for the fused screening test (csrc/full_tiled.h, "TEST screens")
 #define TEST_SCREEN_FACTOR 1.000002f
 // particles (= threads) of one workgroup of the tiled FULL-mode passes
@@ -69,11 +69,11 @@ struct SlabZone {
 #define TILE_THREADS 256
 #endif
 enum {
-   TSTAT_OVER = 0,          // [TILE_CANDS] workgroups whose tile exceeds candidate i
-   TSTAT_BLOCKS = 8,        // workgroups counted
-   TSTAT_MAX = 9,           // largest tile
-   TSTAT_GIVEUP_DENSITY = 10, // entries of the give-up lists of the current step
-   TSTAT_GIVEUP_ACCEL = 11,
+   TSTAT_OVER = 0,            // [TILE_CANDS] workgroups whose tile exceeds candidate i
+   TSTAT_BLOCKS = 12,         // workgroups counted
+   TSTAT_MAX = 13,            // largest tile
+   TSTAT_GIVEUP_DENSITY = 14, // entries of the give-up lists of the current step
+   TSTAT_GIVEUP_ACCEL = 15,
    TSTAT_COUNT = 16
 };
 struct TileCaps {
@@ -81,6 +81,7 @@ struct TileCaps {
    int n_cand;
    int cap_density;         // capacities the current step's launches use
    int cap_accel;
+   int wide;                // list entries carry a 14-bit tile index (a capacity above 4064)
 };
 
 #define SPH_DEAD_ID 0xffffffffu
@@ -166,6 +167,7 @@ struct sph_hip_context {
    int tile_cap_forced = 0;        // SPH_HIP_TILE_CAP: fixed capacity for both kernels (tests)
    int density_levels[TILE_CANDS] = {0}, n_density_levels = 0;
    int accel_levels[TILE_CANDS] = {0}, n_accel_levels = 0;
+   int density_per_cu[TILE_CANDS] = {0}, accel_per_cu[TILE_CANDS] = {0};  // workgroups per CU at each level
    TileCaps caps = {};             // candidate capacities + the two chosen for the current step
 
    // REF-mode lists

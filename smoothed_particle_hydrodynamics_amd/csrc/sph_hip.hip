@@ -131,7 +131,7 @@ int check_ctx(sph_hip_context* ctx)
 // allocation granularity of the hardware, which it rounds more finely than the device does
 // (measured: a size it rated 3/CU ran at 2/CU).
 template <class Kernel>
-int tile_levels(Kernel kernel, int bytes_per_entry, int* levels)
+int tile_levels(Kernel kernel, int bytes_per_entry, int* levels, int* per_cu)
 {
    auto blocks_at = [&](int cap) {
       int nb = 0;
@@ -142,22 +142,29 @@ int tile_levels(Kernel kernel, int bytes_per_entry, int* levels)
       }
       return nb;
    };
-   // dynamic LDS beyond 64 KiB would need an opt-in attribute; the 12-bit tile index stops earlier
-   int cap_max = TILE_CAP_MAX;
-   while (cap_max > 256 && (size_t)(cap_max + TILE_PAD) * bytes_per_entry > 60 * 1024) cap_max -= 32;
+   // a workgroup may take the whole LDS of a CU (160 KiB); the 14-bit tile index of wide list
+   // entries stops a little earlier for 12-byte entries
+   int cap_max = TILE_CAP_MAX_WIDE;
+   while (cap_max > 256 && (size_t)(cap_max + TILE_PAD) * bytes_per_entry > 156 * 1024) cap_max -= 32;
    const int cap_min = 1024 - TILE_PAD;
    int n = 0, prev = 0;
-   for (int want = blocks_at(cap_min); want >= 2 && n < TILE_CANDS / 2; want--) {
+   for (int want = blocks_at(cap_min); want >= 1 && n < TILE_CANDS / 2; want--) {
       int lo = cap_min, hi = cap_max;            // largest cap with blocks_at(cap) >= want
       while (lo < hi) {
          const int mid = lo + ((hi - lo) / 32 + 1) / 2 * 32;
          if (blocks_at(mid) >= want) lo = mid;
          else hi = mid - 32;
       }
-      if (lo > prev) levels[n++] = prev = lo;
+      if (lo > prev) {
+         per_cu[n] = want;
+         levels[n++] = prev = lo;
+      }
       if (lo >= cap_max) break;
    }
-   if (n == 0) levels[n++] = 3008;               // no answer from the runtime: a size that fits
+   if (n == 0) {                                 // no answer from the runtime: a size that fits
+      per_cu[n] = 3;
+      levels[n++] = 3008;
+   }
    if (getenv("SPH_HIP_DEBUG")) {
       fprintf(stderr, "sph_hip: tile capacity levels (%d B/entry):", bytes_per_entry);
       for (int l = 0; l < n; l++) fprintf(stderr, " %d (%d/CU)", levels[l], blocks_at(levels[l]));
@@ -166,11 +173,34 @@ int tile_levels(Kernel kernel, int bytes_per_entry, int* levels)
    return n;
 }
 
-// Smallest level that all but ~0.2 % of the workgroups of the latest reported step fit in (the
-// rest are computed untiled, by the first workgroups of the launch: same results).  An untiled
-// workgroup takes ~100 us from start to end however little else there is to do, so launches too
-// short to hide that tolerate none.  Nothing reported yet: the level next to 3008 entries.
-int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, int n)
+// the tiled kernels may ask for all of a CU's LDS as dynamic shared memory
+void allow_large_tiles()
+{
+   static bool done = false;
+   if (done) return;
+   done = true;
+   const int most = 160 * 1024;
+#define SPH_ALLOW(K) (void)hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, most)
+#define SPH_ALLOW_ALL(K)                                                                         \
+   SPH_ALLOW((K<true, true, false>)); SPH_ALLOW((K<true, false, false>));                         \
+   SPH_ALLOW((K<false, true, false>)); SPH_ALLOW((K<false, false, false>));                       \
+   SPH_ALLOW((K<true, true, true>)); SPH_ALLOW((K<true, false, true>));                           \
+   SPH_ALLOW((K<false, true, true>)); SPH_ALLOW((K<false, false, true>))
+   SPH_ALLOW_ALL(k_full_density_tiled);
+   SPH_ALLOW_ALL(k_full_accel_lists);
+#undef SPH_ALLOW_ALL
+#undef SPH_ALLOW
+   (void)hipGetLastError();
+}
+
+// Level with the least expected cost for the workgroups of the latest reported step.  A larger
+// tile means fewer workgroups per CU (relative throughput thr, measured on the 4M dam-break and
+// its breaking variant), a smaller one sends the workgroups that do not fit down the untiled
+// route (several times the work, and ~100 us from start to end however little else there is to
+// do - launches too short to hide that must not have any).  Nothing reported yet: the level next
+// to 3008 entries.
+int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, const int* per_cu, int n,
+               const float* thr, float untiled_cost)
 {
    const int blocks = fb[TSTAT_BLOCKS];
    if (blocks <= 0) {
@@ -178,11 +208,23 @@ int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, int
          if (levels[l] >= 3008) return levels[l];
       return levels[n - 1];
    }
-   const int tolerated = blocks >= 8192 * 256 / TILE_THREADS ? blocks / 512 : 0;
-   for (int l = 0; l < n; l++)
+   const bool hides_untiled = blocks >= 8192 * 256 / TILE_THREADS;
+   int best = levels[n - 1];
+   float best_cost = 1e30f;
+   for (int l = 0; l < n; l++) {
+      int over = blocks;
       for (int c = 0; c < ctx->caps.n_cand; c++)
-         if (ctx->caps.cand[c] == levels[l] && fb[TSTAT_OVER + c] <= tolerated) return levels[l];
-   return levels[n - 1];
+         if (ctx->caps.cand[c] == levels[l]) over = fb[TSTAT_OVER + c];
+      if (over > 0 && !hides_untiled && l + 1 < n) continue;
+      const float f = (float)over / (float)blocks;
+      const int b = per_cu[l] < 1 ? 1 : (per_cu[l] > 6 ? 6 : per_cu[l]);
+      const float cost = (1.0f - f) / thr[b] + untiled_cost * f;
+      if (cost < best_cost) {
+         best_cost = cost;
+         best = levels[l];
+      }
+   }
+   return best;
 }
 
 // Capacities for the step about to be launched (before its k_tile_desc, which lists the
@@ -191,10 +233,11 @@ void pick_tile_caps(sph_hip_context* ctx)
 {
    TileCaps& caps = ctx->caps;
    if (caps.n_cand == 0) {
-      ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true>, DENSITY_TILE_BYTES,
-                                          ctx->density_levels);
-      ctx->n_accel_levels = tile_levels(k_full_accel_lists<true, true>, ACCEL_TILE_BYTES,
-                                        ctx->accel_levels);
+      allow_large_tiles();
+      ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true, false>, DENSITY_TILE_BYTES,
+                                          ctx->density_levels, ctx->density_per_cu);
+      ctx->n_accel_levels = tile_levels(k_full_accel_lists<true, true, false>, ACCEL_TILE_BYTES,
+                                        ctx->accel_levels, ctx->accel_per_cu);
       // candidates = ascending union of both kernels' levels
       int nd = 0, na = 0;
       while ((nd < ctx->n_density_levels || na < ctx->n_accel_levels) && caps.n_cand < TILE_CANDS) {
@@ -208,12 +251,21 @@ void pick_tile_caps(sph_hip_context* ctx)
    }
    if (ctx->tile_cap_forced > 0) {
       caps.cap_density = caps.cap_accel = ctx->tile_cap_forced;
+      caps.wide = ctx->tile_cap_forced > TILE_CAP_MAX;
       return;
    }
    int fb[TSTAT_COUNT];
    for (int i = 0; i < TSTAT_COUNT; i++) fb[i] = ((volatile int*)ctx->tile_feedback)[i];
-   caps.cap_density = pick_level(ctx, fb, ctx->density_levels, ctx->n_density_levels);
-   caps.cap_accel = pick_level(ctx, fb, ctx->accel_levels, ctx->n_accel_levels);
+   // relative throughput by workgroups per CU (index 1..6), and what an untiled workgroup costs
+   // in units of a tiled one
+   static const float density_thr[7] = {0.0f, 0.33f, 0.62f, 0.85f, 0.93f, 0.97f, 1.0f};
+   static const float accel_thr[7] = {0.0f, 0.40f, 0.68f, 0.87f, 0.98f, 1.0f, 1.0f};
+   caps.cap_density = pick_level(ctx, fb, ctx->density_levels, ctx->density_per_cu,
+                                 ctx->n_density_levels, density_thr, 6.0f);
+   caps.cap_accel = pick_level(ctx, fb, ctx->accel_levels, ctx->accel_per_cu, ctx->n_accel_levels,
+                               accel_thr, 8.0f);
+   // both passes of a step read and write the same lists: one entry format for the two
+   caps.wide = caps.cap_density > TILE_CAP_MAX || caps.cap_accel > TILE_CAP_MAX;
    static int debug_left = getenv("SPH_HIP_DEBUG") ? 6 : 0;
    if (debug_left > 0 && debug_left--)
       fprintf(stderr, "sph_hip: %d workgroups, largest tile %d -> capacities %d / %d\n",
@@ -326,17 +378,23 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
 {
    const int cap = ctx->caps.cap_density;
    const size_t lds = (size_t)(cap + TILE_PAD) * DENSITY_TILE_BYTES;
-#define SPH_GO(U, M)                                                                             \
-   hipLaunchKernelGGL((k_full_density_tiled<U, M>), dim3(blocks), dim3(TILE_THREADS), lds,       \
+#define SPH_GO3(U, M, W)                                                                         \
+   hipLaunchKernelGGL((k_full_density_tiled<U, M, W>), dim3(blocks), dim3(TILE_THREADS), lds,    \
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
                       ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
                       ctx->giveup_density, ctx->tile_feedback)
+#define SPH_GO(U, M)                                                                             \
+   do {                                                                                          \
+      if (ctx->caps.wide) SPH_GO3(U, M, true);                                                   \
+      else SPH_GO3(U, M, false);                                                                 \
+   } while (0)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
    else SPH_GO(false, false);
 #undef SPH_GO
+#undef SPH_GO3
 }
 
 void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part,
@@ -345,7 +403,12 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
    const int cap = ctx->caps.cap_accel;
    const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
 #define SPH_GO(U, M)                                                                             \
-   hipLaunchKernelGGL((k_full_accel_lists<U, M>), dim3(blocks), dim3(TILE_THREADS), lds,         \
+   do {                                                                                          \
+      if (ctx->caps.wide) SPH_GO3(U, M, true);                                                   \
+      else SPH_GO3(U, M, false);                                                                 \
+   } while (0)
+#define SPH_GO3(U, M, W)                                                                         \
+   hipLaunchKernelGGL((k_full_accel_lists<U, M, W>), dim3(blocks), dim3(TILE_THREADS), lds,      \
                       st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
                       ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
@@ -355,6 +418,7 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
    else if (ctx->uniform_mass) SPH_GO(false, true);
    else SPH_GO(false, false);
 #undef SPH_GO
+#undef SPH_GO3
 }
 
 int launch_density(sph_hip_context* ctx)
@@ -649,7 +713,7 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_border, hipEventDisableTiming));
       if (const char* v = getenv("SPH_HIP_TILE_CAP")) {
          const int c = atoi(v);
-         if (c > 0) ctx->tile_cap_forced = c < 256 ? 256 : (c > 3008 ? 3008 : c / 32 * 32);  // 48 KiB at most
+         if (c > 0) ctx->tile_cap_forced = c < 256 ? 256 : (c > 8000 ? 8000 : c / 32 * 32);  // 128 KiB at most
       }
    } else {
       CREATE_TRY(dev_alloc(&ctx->order, cap));
@@ -1288,6 +1352,20 @@ int sph_hip_get_energy(sph_hip_context* ctx, float* kinetic, float* potential)
    SPH_TRY(hipStreamSynchronize(ctx->stream));
    if (kinetic) *kinetic = (float)e[0];
    if (potential) *potential = (float)e[1];
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_tile_stats(sph_hip_context* ctx, int32_t out[20])
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (!out || !ctx->tile_feedback) return SPH_HIP_ERR_INVALID;
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   for (int i = 0; i < TSTAT_COUNT; i++) out[i] = ctx->tile_feedback[i];
+   out[16] = ctx->caps.cap_density;
+   out[17] = ctx->caps.cap_accel;
+   out[18] = ctx->caps.wide;
+   out[19] = 0;
    return SPH_HIP_OK;
 }
 

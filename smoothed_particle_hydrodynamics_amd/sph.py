@@ -273,6 +273,15 @@ class SPH:
         acceleration as one interval, in slot 2), TIMING_OFF.  Resets the collected timings."""
         self._check(self._lib.sph_hip_set_timing(self._ctx, int(level)), "sph_hip_set_timing")
 
+    def tileStats(self):
+        """dict of the last step's LDS-tile statistics (sph_hip_get_tile_stats)."""
+        out = (C.c_int32 * 20)()
+        self._check(self._lib.sph_hip_get_tile_stats(self._ctx, C.byref(out)), "sph_hip_get_tile_stats")
+        v = list(out)
+        return {"over_level": v[0:12], "workgroups": v[12], "largest_tile": v[13],
+                "untiled_density": v[14], "untiled_acceleration": v[15],
+                "capacity_density": v[16], "capacity_acceleration": v[17], "wide_entries": v[18]}
+
     def phaseTotals(self):
         """(sum of the six phase times in ms over the step() calls since resetTimings(), steps)"""
         ms = (C.c_double * 6)()

@@ -172,12 +172,13 @@ def test_full_tiled_equals_untiled(oracle, hiplib, monkeypatch):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("cap", ["512", "1504", "2048", "3008"])
+@pytest.mark.parametrize("cap", ["512", "1504", "2048", "3008", "6016"])
 def test_full_any_tile_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
     """The LDS tile capacity is a per-launch performance choice (occupancy levels picked from the
     tile sizes recent steps needed).  SPH_HIP_TILE_CAP pins it: at 512 every workgroup is on the
     give-up lists and computed untiled by the first workgroups of the launch, at 1504 a mix, at
-    3008 none - the results must not depend on it."""
+    3008 none, and 6016 switches the list entries to their wide format (14-bit tile index) - the
+    results must not depend on it."""
     from smoothed_particle_hydrodynamics_amd import scenes
     monkeypatch.setenv("SPH_HIP_TILE_CAP", cap)
     p, pos, vel, mass = scenes.dam_break(60000)
