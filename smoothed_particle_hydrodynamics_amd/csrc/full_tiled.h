@@ -36,7 +36,9 @@
 #define DENSITY_TILE_BYTES 12
 #define ACCEL_TILE_BYTES 16
 // launch bounds = the most workgroups per CU the register budget should allow
+#ifndef DENSITY_BLOCKS
 #define DENSITY_BLOCKS (6 * 256 / TILE_THREADS)
+#endif
 #ifndef ACCEL_BLOCKS
 #define ACCEL_BLOCKS (TILE_THREADS == 256 ? 5 : 2)
 #endif
