@@ -310,7 +310,8 @@ __device__ __forceinline__ f32x2 screen_pair(f32x2 px, f32x2 py, f32x2 pz, f32x2
       dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, minus_h2)));
 }
 
-// TEST step: eight consecutive, 32-byte aligned tile slots t..t+7 -> 8 screening bits (h2 is the
+// TEST step: eight consecutive tile slots t..t+7 (t a multiple of 4: two 16-byte reads per
+// coordinate) -> 8 screening bits (h2 is the
 // widened threshold).  Six independent ds_read_b128 and branch-free packed math; slots outside
 // the lane's range are masked by the caller.
 __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32x2 py, f32x2 pz,
@@ -420,8 +421,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       const uint32_t kbits = ListEntry<WIDE>::tag(kk);
       const int ts = (int)r.s[kk] + D;
       const int te = (int)r.e[kk] + D;
-      // chunks of 32 tile slots starting at an 8-aligned slot; one acceptance bit per slot
-      for (int t0 = (ts < te) ? (ts & ~7) : te; __any(t0 < te); t0 += 32) {
+      // chunks of 32 tile slots starting at a 4-aligned slot; one acceptance bit per slot
+      for (int t0 = (ts < te) ? (ts & ~3) : te; __any(t0 < te); t0 += 32) {
          uint32_t mask = 0;
 #if defined(SPH_ABLATE) && SPH_ABLATE == 2
          if (false) {
