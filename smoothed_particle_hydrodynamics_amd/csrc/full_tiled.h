@@ -32,7 +32,10 @@
 #define TILE_PAD 32                      // slots past the capacity that aligned 8-slot reads may touch
 #define TILE_CAP_MAX (4096 - TILE_PAD)        // tile indices are 12-bit in narrow list entries
 #define TILE_CAP_MAX_WIDE (16384 - TILE_PAD)  // ... 14-bit in wide ones
-#define TILE_BATCH 8                     // 16-byte loads a thread keeps in flight while filling the tile
+#ifndef TILE_BATCH
+#define TILE_BATCH 8
+#endif
+// (TILE_BATCH: 16-byte loads a thread keeps in flight while filling the tile)
 #define DENSITY_TILE_BYTES 12
 #define ACCEL_TILE_BYTES 16
 // launch bounds = the most workgroups per CU the register budget should allow
