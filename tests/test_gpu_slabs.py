@@ -193,7 +193,13 @@ def test_native_rccl_exchange_single_rank(oracle, hiplib):
     p, pos, vel, mass = moving_block(20000, unequal=True)
     s = SL.HipSlab(p, 0, p.full_cells_z, 40000, 4096, device=0, has_left=False, has_right=False)
     s.upload(np.arange(mass.size, dtype=np.uint32), pos, vel, mass, all_masses_equal=False)
-    s.comm_init(SL.rccl_unique_id(), 0, 1)
+    try:
+        ident = SL.rccl_unique_id()
+    except S.SphHipError as e:
+        if "cannot open librccl" in str(e):
+            pytest.skip("no librccl on this box: " + str(e))
+        raise
+    s.comm_init(ident, 0, 1)
     s.comm_selftest()
     s.comm_run(3)
     d = s.download()
