@@ -173,12 +173,10 @@ int tile_levels(Kernel kernel, int bytes_per_entry, int* levels, int* per_cu)
    return n;
 }
 
-// the tiled kernels may ask for all of a CU's LDS as dynamic shared memory
+// the tiled kernels may ask for all of a CU's LDS as dynamic shared memory (set per context: the
+// attribute belongs to the function on the current device)
 void allow_large_tiles()
 {
-   static bool done = false;
-   if (done) return;
-   done = true;
    const int most = 160 * 1024;
 #define SPH_ALLOW(K) (void)hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, most)
 #define SPH_ALLOW_ALL(K)                                                                         \
