@@ -20,6 +20,28 @@
 // Lanes of a wave that hold consecutive particles of the same cell (the common case once the
 // state is cell-sorted) share ONE global atomic: the run's first lane adds the run length and
 // the others take base + their rank in the run.
+// Counting step of the sort for entry i of cell c (all lanes of the wave call it; lanes that
+// are not live pass c = 0xffffffff): run detection across the wave, one atomic per run.
+__device__ __forceinline__ void count_cell_runs(uint32_t c, bool live, int i,
+                                                uint32_t* __restrict__ cell_count,
+                                                uint32_t* __restrict__ slot)
+{
+   const int lane = threadIdx.x & (SPH_WAVE - 1);
+   const uint32_t prev = __shfl_up(c, 1);
+   const bool head = (lane == 0) || (prev != c);
+   const unsigned long long heads = __ballot(head);
+   // position of my run's head = highest set bit of heads at or below my lane
+   const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+   const int head_lane = 63 - __clzll(below);
+   // run length = distance to the next head above head_lane (or wave end)
+   const unsigned long long above = (head_lane == 63) ? 0ull : (heads >> (head_lane + 1));
+   const int run_len = above ? (__ffsll((long long)above)) : (SPH_WAVE - head_lane);
+   uint32_t base = 0;
+   if (live && head) base = atomicAdd(&cell_count[c], (uint32_t)run_len);
+   base = __shfl(base, head_lane);
+   if (live) slot[i] = base + (uint32_t)(lane - head_lane);
+}
+
 // CHECK_DEAD: entries may carry the dead id (only sph_hip_slab_pack writes it); otherwise the
 // velocity/id array is not read at all.
 template <bool WRITE_VOX, bool CHECK_DEAD>
@@ -30,7 +52,6 @@ k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
              int32_t* __restrict__ vox)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-   const int lane = threadIdx.x & (SPH_WAVE - 1);
    const bool live = i < meta[META_N_IN];
    uint32_t c = 0xffffffffu;
    if (live) {
@@ -70,20 +91,7 @@ k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
          vox[3 * i + 2] = cz;
       }
    }
-   // run detection across the wave
-   const uint32_t prev = __shfl_up(c, 1);
-   const bool head = (lane == 0) || (prev != c);
-   const unsigned long long heads = __ballot(head);
-   // position of my run's head = highest set bit of heads at or below my lane
-   const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-   const int head_lane = 63 - __clzll(below);
-   // run length = distance to the next head above head_lane (or wave end)
-   const unsigned long long above = (head_lane == 63) ? 0ull : (heads >> (head_lane + 1));
-   const int run_len = above ? (__ffsll((long long)above)) : (SPH_WAVE - head_lane);
-   uint32_t base = 0;
-   if (live && head) base = atomicAdd(&cell_count[c], (uint32_t)run_len);
-   base = __shfl(base, head_lane);
-   if (live) slot[i] = base + (uint32_t)(lane - head_lane);
+   count_cell_runs(c, live, i, cell_count, slot);
 }
 
 // ---- 2. exclusive scan of cell counts ------------------------------------------------------

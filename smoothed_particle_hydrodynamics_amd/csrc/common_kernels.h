@@ -2,6 +2,7 @@
 // neighbour-count statistics.
 #pragma once
 
+#include "cell_build.h"
 #include "pair_math.h"
 
 #define RED_THREADS 256
@@ -103,21 +104,35 @@ __device__ __forceinline__ void integrate_particle(const PairConsts& k, float4& 
 
 // KE/PE contributions are reduced per block in double (the reference's serial fp32 running sum
 // is order dependent).
-template <bool UNIT_SCALE>
+// HASH: the context holds the whole grid and exchanges with nobody, so the sorted state this
+// kernel leaves is exactly the input of the next cell build: the build's first step (cell id,
+// counting atomics - k_hash_count) is done here, on the position just computed, and the next
+// build starts at its scan.  One launch and one read of the positions less per step.
+template <bool UNIT_SCALE, bool HASH>
 __global__ void __launch_bounds__(RED_THREADS)
 k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* __restrict__ acc,
-            const int32_t* __restrict__ meta, PairConsts k, double* __restrict__ epart)
+            const int32_t* __restrict__ meta, PairConsts k, double* __restrict__ epart, CellGrid g,
+            uint32_t* __restrict__ key, uint32_t* __restrict__ slot,
+            uint32_t* __restrict__ cell_count)
 {
    // owned particles only: ghosts are integrated by the slab that owns them
    const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
    double ke = 0.0, pe = 0.0;
-   if (p < meta[META_OWN_END]) {
+   const bool live = p < meta[META_OWN_END];
+   uint32_t c = 0xffffffffu;
+   if (live) {
       float4 x = posm[p];
       float4 v = velp[p];
       integrate_particle<UNIT_SCALE>(k, x, v, acc[p], ke, pe);
       posm[p] = x;
       velp[p] = v;
+      if (HASH) {
+         int cx, cy, cz;
+         c = cell_of(g, x.x, x.y, x.z, cx, cy, cz);
+         key[p] = c;
+      }
    }
+   if (HASH) count_cell_runs(c, live, p, cell_count, slot);
    // block reduction, fixed order
    __shared__ double s_ke[RED_THREADS / SPH_WAVE], s_pe[RED_THREADS / SPH_WAVE];
 #pragma unroll

@@ -150,6 +150,8 @@ struct sph_hip_context {
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
+   int prehashed = 0;              // the last integrate also did the next build's cell hash + counts
+   int had_exchange = 0;           // pack/unpack/step_begin were used on this context: never prehash
    int may_hold_dead = 0;          // sph_hip_slab_pack has marked entries dead since the last cell build
    int early_exchange = 0;         // the last step packed its messages early (sph_hip_slab_step_begin)
    struct SlabComm* comm = nullptr;     // native RCCL exchange (csrc/slab_rccl.h), or null

@@ -67,6 +67,13 @@ PairConsts pair_consts(const sph_hip_params& p)
 
 bool unit_scale(const sph_hip_params& p) { return p.sim_scale == 1.0f && p.sim_scale_inv == 1.0f; }
 
+// environment switch "NAME=1", read once per name
+bool getenv_flag(const char* name)
+{
+   const char* v = getenv(name);
+   return v && v[0] == '1';
+}
+
 template <typename T>
 hipError_t dev_alloc(T** ptr, size_t count)
 {
@@ -294,7 +301,9 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    hipStream_t st = ctx->stream;
    const int cur = ctx->cur;
    const SlabZone zone = slab_zone(ctx);
-   if (ctx->mode == SPH_HIP_MODE_REF)
+   if (ctx->prehashed) {
+      ctx->prehashed = 0;   // the last integrate hashed and counted this very state already
+   } else if (ctx->mode == SPH_HIP_MODE_REF)
       hipLaunchKernelGGL((k_hash_count<true, false>), dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
                          ctx->velp[cur], ctx->meta, g, zone, ctx->key, ctx->slot, ctx->cell_count,
                          ctx->vox);
@@ -477,22 +486,37 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
    return SPH_HIP_OK;
 }
 
-int launch_integrate(sph_hip_context* ctx)
+// with_hash: the kernel also does the first step of the next cell build (see k_integrate)
+int launch_integrate(sph_hip_context* ctx, bool with_hash = false)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
    const PairConsts k = pair_consts(ctx->prm);
    const int blocks = div_up(n, RED_THREADS);
-   if (unit_scale(ctx->prm))
-      hipLaunchKernelGGL(k_integrate<true>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k,
-                         ctx->epart + 2);
-   else
-      hipLaunchKernelGGL(k_integrate<false>, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,
-                         ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k,
-                         ctx->epart + 2);
+#define SPH_GO(U, H)                                                                             \
+   hipLaunchKernelGGL((k_integrate<U, H>), dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,       \
+                      ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->acc, ctx->meta, k,           \
+                      ctx->epart + 2, ctx->grid, ctx->key, ctx->slot, ctx->cell_count)
+   const bool unit = unit_scale(ctx->prm);
+   if (unit && with_hash) SPH_GO(true, true);
+   else if (unit) SPH_GO(true, false);
+   else if (with_hash) SPH_GO(false, true);
+   else SPH_GO(false, false);
+#undef SPH_GO
    ctx->energy_blocks = blocks;  // totals are formed on demand (sph_hip_get_energy)
+   ctx->prehashed = with_hash ? 1 : 0;
    SPH_TRY(hipGetLastError());
+   return SPH_HIP_OK;
+}
+
+// The state is about to change behind the back of a prehash (upload, exchange, stand-alone
+// integrate): forget it, and clear the counts it left in the histogram.
+int drop_prehash(sph_hip_context* ctx)
+{
+   if (!ctx->prehashed) return SPH_HIP_OK;
+   ctx->prehashed = 0;
+   SPH_TRY(hipMemsetAsync(ctx->cell_count, 0, ((size_t)ctx->scan_tiles * SCAN_TILE + 16) * sizeof(uint32_t),
+                          ctx->stream));
    return SPH_HIP_OK;
 }
 
@@ -523,7 +547,11 @@ int step_impl(sph_hip_context* ctx, bool timed)
    if (phases) SPH_TRY(hipEventRecord(ev[3], st));
    if ((rc = launch_accel(ctx))) return rc;
    if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
-   if ((rc = launch_integrate(ctx))) return rc;
+   // a context that holds the whole grid and has never exchanged anything: the integrate also
+   // hashes and counts for the next cell build
+   const bool hash_too = ctx->mode == SPH_HIP_MODE_FULL && !ctx->had_exchange && ctx->plane_lo == 0 &&
+                         ctx->plane_hi == ctx->grid.nz_global && !getenv_flag("SPH_HIP_NO_PREHASH");
+   if ((rc = launch_integrate(ctx, hash_too))) return rc;
    if (phases) SPH_TRY(hipEventRecord(ev[6], st));
    if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;
    return SPH_HIP_OK;
@@ -799,6 +827,8 @@ static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const floa
       ctx->err = "upload: more particles than the context capacity";
       return SPH_HIP_ERR_CAPACITY;
    }
+   int rc_prehash = drop_prehash(ctx);
+   if (rc_prehash) return rc_prehash;
    // a slab's entry count changes every step, so its launches are sized by the capacity
    const bool whole = ctx->plane_lo == 0 && ctx->plane_hi == ctx->grid.nz_global;
    ctx->n = whole ? n : ctx->capacity;
@@ -961,6 +991,8 @@ int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_devic
    if (rc) return rc;
    if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
    hipStream_t st = ctx->stream;
+   ctx->had_exchange = 1;
+   if ((rc = drop_prehash(ctx))) return rc;
    ctx->early_exchange = 0;  // this pack sees every particle after the integrate
    ctx->may_hold_dead = 1;   // ... and marks the ones to drop with the dead id
    if (left_device) SPH_TRY(hipMemsetAsync(left_device, 0, sizeof(int32_t) * SLAB_HEADER_INTS, st));
@@ -979,6 +1011,8 @@ int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const voi
    int rc = check_ctx(ctx);
    if (rc) return rc;
    if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
+   ctx->had_exchange = 1;
+   if ((rc = drop_prehash(ctx))) return rc;
    // entries behind the live ones; n_in = n_live + what the messages hold
    hipLaunchKernelGGL(k_slab_unpack, dim3(div_up(2 * capacity_records, 256) + 1), dim3(256), 0,
                       ctx->stream, (const SlabMsg*)left_device, (const SlabMsg*)right_device,
@@ -1003,6 +1037,8 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
       ctx->err = "sph_hip_slab_step_begin: one message buffer per existing neighbour, no other";
       return SPH_HIP_ERR_INVALID;
    }
+   ctx->had_exchange = 1;
+   if ((rc = drop_prehash(ctx))) return rc;
    hipStream_t st = ctx->stream;
    hipStream_t side = exchange_stream ? (hipStream_t)exchange_stream : st;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
@@ -1275,7 +1311,9 @@ int sph_hip_compute_acceleration(sph_hip_context* ctx)
 int sph_hip_integrate(sph_hip_context* ctx)
 {
    int rc = check_ctx(ctx);
-   return rc ? rc : launch_integrate(ctx);
+   if (rc) return rc;
+   if ((rc = drop_prehash(ctx))) return rc;   // the state moves on without a new hash
+   return launch_integrate(ctx);
 }
 
 int sph_hip_synchronize(sph_hip_context* ctx)

@@ -297,3 +297,39 @@ def test_full_long_run_adaptive_capacity_equals_fixed(hiplib, monkeypatch):
     assert moved > 0.01, "the column is meant to move (moved %g)" % moved
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+def test_full_step_then_phase_calls_and_uploads(oracle, hiplib):
+    """sph_hip_step of a whole-grid context leaves the next build's cell hash done (inside the
+    integrate kernel).  Everything that changes the state behind that - a stand-alone integrate,
+    the phase calls, a new upload - must not see stale counts: mixed sequences against the same
+    sequences built from the oracle's phases."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(40000)
+    op = to_oracle_params(p)
+    opos, ovel = pos.copy(), vel.copy()
+    with S.SPH(mass.size, p) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.step()                                           # leaves a prehash
+        ref = oracle.step(op, opos, ovel, mass, mode="full")
+        sph.integrate()                                      # same accelerations applied again
+        oracle.integrate(op, opos, ovel, ref["acc"], mass)
+        sph.step()                                           # must hash the moved state itself
+        ref = oracle.step(op, opos, ovel, mass, mode="full")
+        part = sph.getParticles()
+        assert np.array_equal(part.mPosition, opos) and np.array_equal(part.mAcceleration, ref["acc"])
+        sph.voxelizeParticles(); sph.findNeighbors(); sph.computeDensity()   # consumes the prehash
+        sph.computeAcceleration(); sph.integrate()
+        ref = oracle.step(op, opos, ovel, mass, mode="full")
+        sph.step()
+        ref = oracle.step(op, opos, ovel, mass, mode="full")
+        part = sph.getParticles()
+        assert np.array_equal(part.mPosition, opos) and np.array_equal(part.mDensity, ref["rho"])
+        sph.setParticles(pos, vel, mass)                     # upload over a pending prehash
+        opos, ovel = pos.copy(), vel.copy()
+        sph.run(2)
+        for _ in range(2):
+            ref = oracle.step(op, opos, ovel, mass, mode="full")
+        check_state(sph.getParticles(), ref)
+        assert np.array_equal(sph.getParticles().mPosition, opos)
