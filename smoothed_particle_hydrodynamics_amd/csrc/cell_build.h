@@ -13,6 +13,9 @@
 #include "sph_device.h"
 
 #define SCAN_THREADS 256
+#ifndef RANK_UNROLL
+#define RANK_UNROLL 4   // cell members compared per trip of the in-cell ranking (FULL mode)
+#endif
 #define SCAN_ITEMS 16
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
@@ -286,15 +289,15 @@ rank_gather(int p, const uint32_t* __restrict__ perm, const uint32_t* __restrict
    const float4 v = velp_in[i];
    const uint32_t id = __float_as_uint(v.w);
    uint32_t rank = 0;
-   // four cell members per trip: their two dependent loads (perm, then id) overlap
-   for (uint32_t q0 = s; q0 < e; q0 += 4) {
-      uint32_t other[4];
+   // RANK_UNROLL cell members per trip: their two dependent loads (perm, then id) overlap
+   for (uint32_t q0 = s; q0 < e; q0 += RANK_UNROLL) {
+      uint32_t other[RANK_UNROLL];
 #pragma unroll
-      for (int u = 0; u < 4; u++) other[u] = perm[q0 + u < e ? q0 + u : e - 1];
+      for (int u = 0; u < RANK_UNROLL; u++) other[u] = perm[q0 + u < e ? q0 + u : e - 1];
 #pragma unroll
-      for (int u = 0; u < 4; u++) other[u] = __float_as_uint(velp_in[other[u]].w);
+      for (int u = 0; u < RANK_UNROLL; u++) other[u] = __float_as_uint(velp_in[other[u]].w);
 #pragma unroll
-      for (int u = 0; u < 4; u++) rank += (q0 + u < e && other[u] < id) ? 1u : 0u;
+      for (int u = 0; u < RANK_UNROLL; u++) rank += (q0 + u < e && other[u] < id) ? 1u : 0u;
    }
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;
