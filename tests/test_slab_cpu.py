@@ -121,3 +121,21 @@ def test_distributed_slabs_equal_single_domain(oracle, tmp_path, world, overlap)
         migrated += int(np.abs(np.diff(h)).sum())
     assert seen.all()
     assert migrated > 0, "the scene is meant to move particles across the cuts"
+
+
+def test_scene_subsets_match_the_whole_scene():
+    """bench.py's ranks generate only their own slab: any coordinate axis or subset of rows of the
+    counter-based scene must equal the corresponding part of the whole scene, and the parameters
+    must not depend on whether particles were generated."""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    n = 20000
+    p, pos, vel, mass = scenes.dam_break(n, box=(1.0, 1.0, 3.0))
+    p2, hi = scenes.dam_break_params(n, box=(1.0, 1.0, 3.0))
+    assert bytes(p) == bytes(p2)
+    for axis in range(3):
+        a = scenes.box_fill_axis(n, (0.0, 0.0, 0.0), hi, axis)
+        assert np.array_equal(a, pos.reshape(-1, 3)[:, axis])
+    ids = np.array([0, 1, 17, 4096, n - 1, 12345], np.int64)
+    sub = scenes.box_fill_subset(ids, (0.0, 0.0, 0.0), hi).reshape(-1, 3)
+    assert np.array_equal(sub, pos.reshape(-1, 3)[ids])
+    assert not vel.any() and (mass == 1.0).all()
