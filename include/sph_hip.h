@@ -27,14 +27,18 @@
 extern "C" {
 #endif
 
-#define SPH_HIP_ABI_VERSION 3
+#define SPH_HIP_ABI_VERSION 4
+/* The ABI version the loaded library was built with (compare with SPH_HIP_ABI_VERSION of the
+ * header the host was compiled against before calling anything else). */
+int sph_hip_abi_version(void);
 
 typedef enum sph_hip_status {
    SPH_HIP_OK = 0,
    SPH_HIP_ERR_INVALID = -1,   /* bad argument / bad state */
    SPH_HIP_ERR_DEVICE = -2,    /* a HIP runtime call failed */
    SPH_HIP_ERR_CAPACITY = -3,  /* more particles than the context was created for */
-   SPH_HIP_ERR_NO_DEVICE = -4  /* no usable gfx950 device */
+   SPH_HIP_ERR_NO_DEVICE = -4, /* no usable gfx950 device */
+   SPH_HIP_ERR_EXCHANGE = -5   /* a slab exchange lost particles (sph_hip_slab_status bits) */
 } sph_hip_status;
 
 /* Neighbour semantics of a context.
@@ -281,6 +285,23 @@ int sph_hip_slab_comm_selftest(sph_hip_context* ctx);
  * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded,
  * 8: a particle missed the early exchange). */
 int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors);
+/* The same error bits without draining the stream: reports what the copy requested by the
+ * PREVIOUS call brought (*errors, may be NULL; waits for that one copy if the host has run more
+ * than one polling interval ahead of the device) and requests the next copy of the device's
+ * error word into pinned host memory.  Returns SPH_HIP_ERR_EXCHANGE (message in
+ * sph_hip_last_error) once a non-zero word has arrived, so a loop that calls this every K steps
+ * stops within 2 K steps of the exchange going wrong instead of running on with missing particles.
+ * sph_hip_slab_comm_run polls every 16 steps itself; sph_hip_synchronize and
+ * sph_hip_slab_download check after waiting and return the same status. */
+int sph_hip_slab_poll_errors(sph_hip_context* ctx, int32_t* errors);
+
+/* ---- self tests -------------------------------------------------------------------------- */
+
+/* The pair loops take square roots with a shorter instruction sequence than the compiler's
+ * sqrtf (csrc/sph_device.h: sqrt_rn).  This compares the two for EVERY non-negative finite
+ * float on `device` (2^31 inputs, well under a second): *mismatches = how many differ,
+ * *first_bad = bit pattern of the smallest one that does (0xffffffff if none). */
+int sph_hip_selftest_sqrt(int device, uint64_t* mismatches, uint32_t* first_bad);
 
 /* ---- streams ----------------------------------------------------------------------------- */
 

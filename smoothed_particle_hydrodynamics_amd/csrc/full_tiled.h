@@ -417,7 +417,13 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 
    const float h2_screen = k.h2_screen;
    int count = 0;
-   uint32_t hold = 0;  // an even-numbered entry waiting for its partner
+   // The list is a column of 16-bit entries: entry j of this lane is the (j & 1) half of word
+   // (j >> 1) * TILE_THREADS + tid.  TEST stores every accepted neighbour with one 2-byte store
+   // (no pairing of entries in registers: the append loop runs to the largest popcount among the
+   // wave's lanes for every chunk, so what counts is instructions per trip).  half = index of the
+   // next entry in units of 16 bits from the lane's first one; step alternates 1 / 2 * TILE_THREADS - 1.
+   uint16_t* const my_entries = reinterpret_cast<uint16_t*>(list_block + tid);
+   uint32_t half = 0, step = 1;
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = sd.D[kk];
@@ -445,39 +451,38 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
             }
             // a list that would overflow stops growing here (checked per chunk, not per entry):
-            // the workgroup gives up its lists anyway
-            if (count + __builtin_popcount(mask) > NLIST_CAP) {
+            // the particle goes without a list anyway
+            count += __builtin_popcount(mask);
+            if (count > NLIST_CAP) {
                mask = 0u;
                count = NLIST_CAP + 1;
             }
          }
-         // append the set bits, ascending, to the lane's neighbour list: an even entry waits in
-         // a register, an odd one completes a 32-bit word and stores it (half the scattered
-         // stores)
 #if defined(SPH_ABLATE) && SPH_ABLATE == 9
-         count += __builtin_popcount(mask);   // timing only: no lists
-         mask = 0u;
+         mask = 0u;   // timing only: no lists
 #endif
+         // append the set bits, ascending, to the lane's neighbour list
+         const uint32_t ebase = kbits | (uint32_t)t0;
          while (__any(mask != 0u)) {
 #pragma unroll
             for (int rep = 0; rep < APPEND_POPS; rep++) {   // several pops per trip: less loop control
                if (mask != 0u) {
                   const uint32_t bit = (uint32_t)__builtin_ctz(mask);
                   mask &= mask - 1u;
-                  const uint32_t entry = kbits | ((uint32_t)t0 + bit);
-                  if (count & 1) {
-                     list_block[((uint32_t)count >> 1) * TILE_THREADS + (uint32_t)tid] = hold | (entry << 16);
-                  } else {
-                     hold = entry;
-                  }
-                  count++;
+#if defined(SPH_ABLATE) && SPH_ABLATE == 10
+                  count ^= (int)(ebase + bit) & (int)half & 1;   // timing only: no store
+#elif defined(SPH_ABLATE) && SPH_ABLATE == 11
+                  my_entries[0] = (uint16_t)(ebase + bit);        // timing only: every store to the lane's first word
+#else
+                  my_entries[half] = (uint16_t)(ebase + bit);
+#endif
+                  half += step;
+                  step = 2 * TILE_THREADS - step;
                }
             }
          }
       }
    }
-   if ((count & 1) && count < NLIST_CAP)
-      list_block[((uint32_t)count >> 1) * TILE_THREADS + (uint32_t)tid] = hold;
    // A particle with more neighbours than its list holds (a scene many times denser than the
    // benchmark's) goes without a list: its lane walks its candidate ranges in the tile one by one
    // here - canonical order, small code - and again in the acceleration pass, which recognises it
@@ -510,7 +515,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
                float mj = pi.w;
                if (!UNIFORM_MASS) mj = posm[t - D].w;
-               float d = sqrtf(d2);
+               float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                density_accumulate(k, mj, d, density);
                count++;
@@ -543,7 +548,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
             if (d2 < k.h2) {             // the reference's own test, on the reference's own value
-               float d = sqrtf(d2);
+               float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                density_accumulate(k, mj, d, density);
             } else {
@@ -558,24 +563,21 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       // entries per word in, two per word out; the write position never passes the read position)
       if (screened_wrongly) {
          int kept = 0;
-         uint32_t out_hold = 0;
          for (int j = 0; j < count; j += 2) {
             const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-               if (j + half < count) {
-                  const uint32_t entry = half ? word >> 16 : word & 0xffffu;
+            for (int hf = 0; hf < 2; hf++) {
+               if (j + hf < count) {
+                  const uint32_t entry = hf ? word >> 16 : word & 0xffffu;
                   const int t = ListEntry<WIDE>::tile(entry);
                   float dx, dy, dz;
                   if (dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz) < k.h2) {
-                     if (kept & 1) list_block[((uint32_t)kept >> 1) * TILE_THREADS + (uint32_t)tid] = out_hold | (entry << 16);
-                     else out_hold = entry;
+                     my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry;
                      kept++;
                   }
                }
             }
          }
-         if (kept & 1) list_block[((uint32_t)kept >> 1) * TILE_THREADS + (uint32_t)tid] = out_hold;
          count = kept;
       }
    }
@@ -800,7 +802,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             const float4 pj = xyzc[ListEntry<WIDE>::tile(entry[u])];
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
-            float d = sqrtf(d2);
+            float d = sqrt_rn(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
             accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
                                    pj.w, in_range);
@@ -823,7 +825,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
-               float d = sqrtf(d2);
+               float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                const float4 vj = velB[t - D];
                float mj = pi.w;

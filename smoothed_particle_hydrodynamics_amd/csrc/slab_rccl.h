@@ -34,12 +34,21 @@ inline const RcclApi* rccl_api(std::string* why)
    static std::string failure;
    if (!tried) {
       tried = true;
+      // SPH_HIP_RCCL_LIBRARY names the one library to try instead of the usual places (a site
+      // with its own RCCL build; the tests use it to reach the not-found branch)
+      const char* forced = getenv("SPH_HIP_RCCL_LIBRARY");
+      std::string last_error = "?";
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-         api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+         (void)dlerror();
+         api.lib = dlopen(forced ? forced : name, RTLD_NOW | RTLD_GLOBAL);
          if (api.lib) break;
+         // dlerror() clears the message it returns: call it once per failure
+         const char* m = dlerror();
+         if (m) last_error = m;
+         if (forced) break;
       }
       if (!api.lib) {
-         failure = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?");
+         failure = std::string("cannot open librccl: ") + last_error;
       } else {
 #define SPH_RCCL_SYM(field, name)                                                   \
    if (failure.empty()) {                                                          \

@@ -183,6 +183,11 @@ struct sph_hip_context {
    int energy_blocks = 0;   // partials written by the last integrate (0 = none yet)
    int32_t* stats = nullptr; // sum(lo,hi), max, min
 
+   // error word of the slab exchange as last copied to the host (pinned; sph_hip_slab_poll_errors)
+   volatile int32_t* err_watch = nullptr;
+   hipEvent_t watch_event = nullptr;  // behind the last requested copy of the error word
+   int watch_pending = 0;
+
    // staging for host <-> device in the reference's interleaved layouts
    float* stage = nullptr; // capacity * 11 floats
 };
@@ -216,6 +221,35 @@ __device__ __forceinline__ uint32_t cell_of(const CellGrid& g, float x, float y,
    if (cz < 0 || cz >= g.nz) return (uint32_t)g.ncells;
    return (uint32_t)((cz * g.ny + cy) * g.nx + cx);
 }
+
+// Correctly rounded fp32 square root for the hot pair loops: the same value sqrtf() returns
+// (IEEE round-to-nearest-even; checked against it for EVERY non-negative finite float by
+// sph_hip_selftest_sqrt / tests/test_gpu_full_mode.py), in 10 instructions instead of the 15 of
+// the compiler's expansion (v_sqrt_f32 + two +-1 ulp residual checks + denormal rescaling).
+// Reciprocal-square-root seed, one coupled Goldschmidt step for g ~ sqrt(x) and h ~ 1/(2 sqrt(x)),
+// then Markstein's correction g + (x - g*g) * h, whose fused residual makes the last rounding the
+// only one that matters.  x = 0 gives 0 (the seed is taken of max(x, FLT_MIN), so g = 0 * finite).
+// Below 2^-102 the residual x - g*g leaves the normal range and the sweep finds 1.8 million
+// inputs that round the other way (none above): those, and denormals, take sqrtf() - a squared
+// distance that small needs two fp32 positions 2^-51 apart, so the branch is there for
+// correctness, not for speed.
+#ifndef SPH_SQRT_GENERIC
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+   // bits in [1, 0x0c7fffff]  <=>  0 < x < 2^-102  (x is never negative here; -0 and 0 pass)
+   if (__builtin_expect(__any(__float_as_uint(x) - 1u < 0x0c7fffffu), 0)) return sqrtf(x);
+   const float y = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));
+   float g = x * y;
+   float h = 0.5f * y;
+   const float r = __builtin_fmaf(-h, g, 0.5f);
+   g = __builtin_fmaf(g, r, g);
+   h = __builtin_fmaf(h, r, h);
+   const float d = __builtin_fmaf(-g, g, x);
+   return __builtin_fmaf(d, h, g);
+}
+#else
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+#endif
 
 // fp32 squared distance with the reference's association: (dx*dx + dy*dy) + dz*dz, no FMA
 // (the translation unit is compiled with -ffp-contract=off).

@@ -115,6 +115,8 @@ void free_all(sph_hip_context* ctx)
    if (ctx->ev_density) (void)hipEventDestroy(ctx->ev_density);
    if (ctx->ev_border) (void)hipEventDestroy(ctx->ev_border);
    if (ctx->tile_feedback) (void)hipHostFree(ctx->tile_feedback);
+   if (ctx->err_watch) (void)hipHostFree((void*)ctx->err_watch);
+   if (ctx->watch_event) (void)hipEventDestroy(ctx->watch_event);
    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 }
 
@@ -572,9 +574,87 @@ int read_phases(sph_hip_context* ctx, hipEvent_t* ev, float ms[6])
    return SPH_HIP_OK;
 }
 
+// ---- error word of the slab exchange, watched without draining the stream ------------------------
+// Request a copy of meta[META_ERRORS] into the pinned watch word.  Before that, wait for the
+// PREVIOUS request (made one polling interval ago): normally long done; when the host has run far
+// ahead of the device it holds the host back to at most two intervals of queued steps, which is
+// what makes "reported within two intervals" true.
+int watch_enqueue(sph_hip_context* ctx)
+{
+   if (ctx->watch_pending) SPH_TRY(hipEventSynchronize(ctx->watch_event));
+   SPH_TRY(hipMemcpyAsync((void*)ctx->err_watch, ctx->meta + META_ERRORS, sizeof(int32_t),
+                          hipMemcpyDeviceToHost, ctx->stream));
+   SPH_TRY(hipEventRecord(ctx->watch_event, ctx->stream));
+   ctx->watch_pending = 1;
+   return SPH_HIP_OK;
+}
+
+// what the last arrived copy said
+int watch_check(sph_hip_context* ctx, const char* who)
+{
+   const int32_t bits = ctx->err_watch[0];
+   if (bits == 0) return SPH_HIP_OK;
+   char text[256];
+   snprintf(text, sizeof(text),
+            "%s: the slab exchange lost particles, error bits %d (1 entry outside slab and halo, "
+            "2 message overflow, 4 context capacity, 8 missed by the early exchange)", who, (int)bits);
+   ctx->err = text;
+   return SPH_HIP_ERR_EXCHANGE;
+}
+
+__global__ void k_selftest_sqrt(unsigned long long* __restrict__ out)
+{
+   // every non-negative finite float: bit patterns 0 .. 0x7f7fffff
+   unsigned long long bad = 0;
+   uint32_t first = 0xffffffffu, last = 0u;
+   const uint32_t stride = gridDim.x * blockDim.x;
+   for (uint64_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= 0x7f7fffffull; b += stride) {
+      const float x = __uint_as_float((uint32_t)b);
+      const float want = sqrtf(x), got = sqrt_rn(x);
+      if (__float_as_uint(want) != __float_as_uint(got)) {
+         bad++;
+         first = min(first, (uint32_t)b);
+         last = max(last, (uint32_t)b);
+      }
+   }
+   if (bad) {
+      atomicAdd(&out[0], bad);
+      atomicMin(&out[1], (unsigned long long)first);
+      atomicMax(&out[2], (unsigned long long)last);
+   }
+}
+
 } // namespace
 
 extern "C" {
+
+int sph_hip_abi_version(void) { return SPH_HIP_ABI_VERSION; }
+
+int sph_hip_selftest_sqrt(int device, uint64_t* mismatches, uint32_t* first_bad)
+{
+   if (hipSetDevice(device) != hipSuccess) {
+      g_create_error = "sph_hip_selftest_sqrt: no such device";
+      return SPH_HIP_ERR_NO_DEVICE;
+   }
+   unsigned long long* d = nullptr;
+   unsigned long long h[3] = {0ull, 0xffffffffull, 0ull};
+   if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess ||
+       hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+      g_create_error = "sph_hip_selftest_sqrt: device memory";
+      return SPH_HIP_ERR_DEVICE;
+   }
+   hipLaunchKernelGGL(k_selftest_sqrt, dim3(256 * 16), dim3(256), 0, 0, d);
+   const hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+   (void)hipFree(d);
+   if (e != hipSuccess) {
+      g_create_error = std::string("sph_hip_selftest_sqrt: ") + hipGetErrorString(e);
+      return SPH_HIP_ERR_DEVICE;
+   }
+   if (mismatches) *mismatches = h[0];
+   if (first_bad) *first_bad = (uint32_t)h[1];
+   if (getenv("SPH_HIP_DEBUG")) fprintf(stderr, "sph_hip_selftest_sqrt: %llu differ, bits 0x%08llx .. 0x%08llx\n", h[0], h[1], h[2]);
+   return SPH_HIP_OK;
+}
 
 int sph_hip_params_default(sph_hip_params* p, float h, int cells_x, int cells_y, int cells_z)
 {
@@ -658,6 +738,15 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    if (g.nx < 1 || g.ny < 1 || g.nz_global < 1 || plane_lo < 0 || plane_hi > g.nz_global ||
        plane_lo >= plane_hi || (mode == SPH_HIP_MODE_REF && (plane_lo != 0 || plane_hi != g.nz_global))) {
       g_create_error = "sph_hip_create: bad grid shape or slab range";
+      delete ctx;
+      return SPH_HIP_ERR_INVALID;
+   }
+   // A slab with a neighbour feeds that neighbour's `halo` ghost planes from its own planes, and
+   // the ghost planes of the two sides must not overlap in what they send: 2 * halo planes at
+   // least (slab.plan_cuts plans with the same minimum).  A thinner slab would leave its
+   // neighbour's ghosts incomplete without any error bit being raised.
+   if (halo > 0 && (plane_lo > 0 || plane_hi < g.nz_global) && plane_hi - plane_lo < 2 * halo) {
+      g_create_error = "sph_hip_create_slab: a slab next to another needs at least 2 * SPH_HIP_SLAB_HALO planes";
       delete ctx;
       return SPH_HIP_ERR_INVALID;
    }
@@ -750,6 +839,9 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    CREATE_TRY(dev_alloc(&ctx->epart, (size_t)2 * ctx->eblocks + 2));
    CREATE_TRY(hipMemsetAsync(ctx->epart, 0, sizeof(double) * 2, ctx->stream));
    CREATE_TRY(dev_alloc(&ctx->stats, 4));
+   CREATE_TRY(hipHostMalloc((void**)&ctx->err_watch, 4 * sizeof(int32_t), hipHostMallocDefault));
+   for (int i = 0; i < 4; i++) ctx->err_watch[i] = 0;
+   CREATE_TRY(hipEventCreateWithFlags(&ctx->watch_event, hipEventDisableTiming));
    CREATE_TRY(dev_alloc(&ctx->stage, cap * 12));
    CREATE_TRY(hipStreamSynchronize(ctx->stream));
 #undef CREATE_TRY
@@ -836,6 +928,8 @@ static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const floa
    ctx->cur = 0;
    ctx->uniform_mass = uniform_mass;
    ctx->ev_steps = 0;
+   ctx->err_watch[0] = 0;   // (the upload clears the device's error word below)
+   ctx->watch_pending = 0;
    // before the first cell build everything uploaded is live and owned, in upload order
    const int32_t meta[META_COUNT] = {n, n, 0, n, 0, n, 0, 0};
    SPH_TRY(hipMemcpyAsync(ctx->meta, meta, sizeof(meta), hipMemcpyHostToDevice, ctx->stream));
@@ -958,7 +1052,10 @@ int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uin
 {
    int rc = check_ctx(ctx);
    if (rc) return rc;
-   if ((rc = owned_count(ctx, nullptr))) return rc;
+   int32_t meta[META_COUNT];
+   if ((rc = owned_count(ctx, meta))) return rc;
+   ctx->err_watch[0] = meta[META_ERRORS];
+   if ((rc = watch_check(ctx, "sph_hip_slab_download"))) return rc;
    if (rows) *rows = ctx->n_owned;
    if (ctx->n_owned > max_rows) {
       ctx->err = "sph_hip_slab_download: caller's arrays are too small";
@@ -977,6 +1074,17 @@ int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int
    if (owned) *owned = meta[META_OWN_END] - meta[META_OWN_BEGIN];
    if (errors) *errors = meta[META_ERRORS];
    return SPH_HIP_OK;
+}
+
+int sph_hip_slab_poll_errors(sph_hip_context* ctx, int32_t* errors)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->watch_pending) SPH_TRY(hipEventSynchronize(ctx->watch_event));
+   ctx->watch_pending = 0;
+   if (errors) *errors = ctx->err_watch[0];
+   if ((rc = watch_check(ctx, "sph_hip_slab_poll_errors"))) return rc;
+   return watch_enqueue(ctx);
 }
 
 size_t sph_hip_slab_message_bytes(int capacity_records)
@@ -1219,6 +1327,15 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
       c->primed = true;
    }
    for (int s = 0; s < steps; s++) {
+      // every 16 steps: ask for the device's error word (asynchronous copy) and look at what the
+      // previous request brought - a run that lost particles stops within 32 steps, with no
+      // synchronisation anywhere
+      if (s % 16 == 0) {
+         if (ctx->watch_pending) SPH_TRY(hipEventSynchronize(ctx->watch_event));
+         ctx->watch_pending = 0;
+         if ((rc = watch_check(ctx, "sph_hip_slab_comm_run"))) return rc;
+         if ((rc = watch_enqueue(ctx))) return rc;
+      }
       // border planes + messages on the exchange stream, transfer behind them; the interior's
       // acceleration and the integrate meanwhile on the context's stream
       if ((rc = sph_hip_slab_step_begin(ctx, c->send_left, c->send_right, c->capacity_records, c->stream)))
@@ -1229,7 +1346,9 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
       SPH_TRY(hipStreamWaitEvent(st, c->arrived, 0));
       if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->capacity_records))) return rc;
    }
-   return SPH_HIP_OK;
+   // the word as it stands after the last step travels behind the loop: the caller's
+   // sph_hip_synchronize (or the next call of this function) reports it
+   return watch_enqueue(ctx);
 }
 
 int sph_hip_slab_comm_selftest(sph_hip_context* ctx)
@@ -1321,6 +1440,13 @@ int sph_hip_synchronize(sph_hip_context* ctx)
    int rc = check_ctx(ctx);
    if (rc) return rc;
    SPH_TRY(hipStreamSynchronize(ctx->stream));
+   if (ctx->had_exchange) {
+      // a slab that exchanges: say so here, where every host waits before it reads results
+      int32_t bits = 0;
+      SPH_TRY(hipMemcpy(&bits, ctx->meta + META_ERRORS, sizeof(bits), hipMemcpyDeviceToHost));
+      ctx->err_watch[0] = bits;
+      return watch_check(ctx, "sph_hip_synchronize");
+   }
    return SPH_HIP_OK;
 }
 

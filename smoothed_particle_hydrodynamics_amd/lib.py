@@ -99,7 +99,11 @@ PROTOTYPES = {
     "sph_hip_slab_comm_run": (C.c_int, [_ctx, C.c_int]),
     "sph_hip_slab_comm_selftest": (C.c_int, [_ctx]),
     "sph_hip_slab_status": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "sph_hip_slab_poll_errors": (C.c_int, [_ctx, _P(C.c_int32)]),
+    "sph_hip_abi_version": (C.c_int, []),
+    "sph_hip_selftest_sqrt": (C.c_int, [C.c_int, _P(C.c_uint64), _P(C.c_uint32)]),
 }
+ABI_VERSION = 4   # SPH_HIP_ABI_VERSION of the include/sph_hip.h these prototypes mirror
 
 _LIB = None
 
@@ -134,6 +138,9 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.sph_hip_abi_version() != ABI_VERSION:
+        raise SphHipError("%s has ABI version %d, this binding expects %d: rebuild it" %
+                          (path, lib.sph_hip_abi_version(), ABI_VERSION))
     _LIB = lib
     return lib
 

@@ -179,6 +179,15 @@ class HipSlab:
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
 
+    def poll_errors(self):
+        """Non-blocking look at the exchange's error bits (sph_hip_slab_poll_errors): raises
+        SphHipError once a copy of a non-zero error word has reached the host; otherwise asks for
+        the next copy and returns the bits seen so far (0)."""
+        e = C.c_int32()
+        self._check(self._lib.sph_hip_slab_poll_errors(self._ctx, C.byref(e)),
+                    "sph_hip_slab_poll_errors")
+        return e.value
+
     def status(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self._lib.sph_hip_slab_status(self._ctx, C.byref(a), C.byref(b), C.byref(c)),
@@ -408,13 +417,25 @@ class DistSlabStepper:
     Both leave the same state behind a step, except that the overlapped loop has already
     exchanged the ghosts for the next one."""
 
+    CHECK_EVERY = 16     # steps between two looks at the slab's error bits (no synchronisation)
+
     def __init__(self, slab, transport, overlap=True):
         self.slab, self.transport = slab, transport
         self.overlap = overlap and hasattr(slab, "step_begin")
         self._primed = False
+        self._steps = 0
+
+    def run(self, steps):
+        for _ in range(steps):
+            self.step()
 
     def step(self):
         slab, tr = self.slab, self.transport
+        # fail loudly: a run that has lost particles (message or capacity overflow, a particle the
+        # early exchange missed) stops within 2 * CHECK_EVERY steps instead of running on
+        if self._steps % self.CHECK_EVERY == 0 and hasattr(slab, "poll_errors"):
+            slab.poll_errors()
+        self._steps += 1
         if not self.overlap:
             slab.pack()
             tr.exchange(slab)
@@ -442,7 +463,10 @@ class LocalSlabGroup:
     Same kernels and message format as the distributed run; used to check on a single GPU that
     results do not depend on the number of slabs."""
 
+    CHECK_EVERY = 16
+
     def __init__(self, slabs, overlap=False, exchange_stream=None):
+        self._steps = 0
         self.slabs = slabs
         self.overlap = overlap       # the early-exchange protocol (sph_hip_slab_step_begin/end)
         # optional second stream for the border work, as in the distributed run (the messages
@@ -457,6 +481,11 @@ class LocalSlabGroup:
             s.unpack(left, right)
 
     def step(self):
+        if self._steps % self.CHECK_EVERY == 0:
+            for s in self.slabs:
+                if hasattr(s, "poll_errors"):
+                    s.poll_errors()
+        self._steps += 1
         if not self.overlap:
             for s in self.slabs:
                 s.pack()

@@ -90,6 +90,53 @@ def test_no_gpu_means_loud_failure_not_fallback(hiplib):
             S.SPH(1024)
 
 
+def test_abi_version_is_exported_and_matches_the_header(hiplib):
+    from smoothed_particle_hydrodynamics_amd import lib as L
+    text = open(os.path.join(ROOT, "include", "sph_hip.h")).read()
+    declared = int(re.search(r"#define\s+SPH_HIP_ABI_VERSION\s+(\d+)", text).group(1))
+    assert hiplib.sph_hip_abi_version() == declared == L.ABI_VERSION
+
+
+def test_missing_rccl_is_an_error_message_not_a_crash():
+    """librccl cannot be opened (here: forced to a name that does not exist): the entry points
+    that need it return an error with the loader's message.  (The branch used to call dlerror()
+    twice - the second call returns NULL - and build a std::string from it.)  Own process: the
+    library looks RCCL up once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from smoothed_particle_hydrodynamics_amd.lib import load_library\n"
+        "lib = load_library()\n"
+        "buf = (C.c_char * 128)()\n"
+        "rc = lib.sph_hip_rccl_unique_id(buf, 128)\n"
+        "print('rc', rc, lib.sph_hip_last_error(None).decode())\n" % ROOT)
+    env = dict(os.environ, SPH_HIP_RCCL_LIBRARY="/nonexistent/librccl-not-here.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rc -1" in out.stdout and "cannot open librccl" in out.stdout
+    assert "librccl-not-here" in out.stdout      # the loader's own text made it through
+
+
+def test_slab_thinner_than_its_halos_is_refused(hiplib):
+    """sph_hip_create_slab: a slab next to another needs 2 * SPH_HIP_SLAB_HALO planes (what
+    slab.plan_cuts plans with); the check comes before any device is touched."""
+    from smoothed_particle_hydrodynamics_amd.lib import default_params
+    p = default_params(0.1, (8, 8, 8))
+    ctx = C.c_void_p()
+    nz = p.full_cells_z
+    assert nz >= 16
+    for lo, hi in ((4, 7), (0, 3), (nz - 2, nz)):
+        rc = hiplib.sph_hip_create_slab(C.byref(ctx), C.byref(p), 1024, 0, lo, hi)
+        msg = hiplib.sph_hip_last_error(None).decode()
+        # without a GPU the device check comes first (-4); with one the thickness check answers
+        assert rc in (-1, -4), (lo, hi, rc)
+        if rc == -1:
+            assert "2 * SPH_HIP_SLAB_HALO" in msg
+
+
 def test_missing_library_is_loud(tmp_path):
     from smoothed_particle_hydrodynamics_amd.lib import SphHipError, load_library
     with pytest.raises(SphHipError, match="no CPU fallback"):

@@ -333,3 +333,14 @@ def test_full_step_then_phase_calls_and_uploads(oracle, hiplib):
             ref = oracle.step(op, opos, ovel, mass, mode="full")
         check_state(sph.getParticles(), ref)
         assert np.array_equal(sph.getParticles().mPosition, opos)
+
+
+def test_pair_loop_square_root_equals_sqrtf_for_every_float(hiplib):
+    """csrc/sph_device.h sqrt_rn (reciprocal-square-root seed + one Goldschmidt step + Markstein's
+    correction) returns what sqrtf returns - IEEE round to nearest, which is what the reference's
+    sqrt() gives (src/sph.cpp:659, 663) - for every non-negative finite fp32 input: the library
+    sweeps all 2^31 of them on the device."""
+    import ctypes as C
+    bad, first = C.c_uint64(123), C.c_uint32(0)
+    assert hiplib.sph_hip_selftest_sqrt(0, C.byref(bad), C.byref(first)) == 0
+    assert bad.value == 0, "%d inputs differ, the smallest has bits 0x%08x" % (bad.value, first.value)

@@ -124,6 +124,42 @@ def test_message_overflow_is_reported(hiplib):
         s.close()
 
 
+def test_a_run_that_loses_particles_stops_loudly(hiplib):
+    """Nobody has to ask: the stepping loop looks at the error bits every 16 steps without
+    synchronising (sph_hip_slab_poll_errors) and raises within 32 steps of the overflow;
+    waiting for the slab (sph_hip_synchronize) and downloading from it raise too."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    p, pos, vel, mass = moving_block(20000, unequal=False)
+    cuts = SL.plan_cuts(p, pos.reshape(-1, 3)[:, 2], 2)
+    import torch
+    stream = torch.cuda.Stream()
+    slabs = []
+    for r in range(2):
+        s = SL.HipSlab(p, cuts[r], cuts[r + 1], 60000, 16, device=0, has_left=r > 0, has_right=r < 1,
+                       stream=stream)
+        s.upload(*SL.split_scene(p, cuts, r, pos, vel, mass), all_masses_equal=True)
+        slabs.append(s)
+    group = SL.LocalSlabGroup(slabs)
+    stopped_at = None
+    for step in range(40):
+        try:
+            group.step()
+        except S.SphHipError as e:
+            assert "lost particles" in str(e) and "error bits" in str(e)
+            stopped_at = step
+            break
+    assert stopped_at is not None and stopped_at <= 2 * SL.LocalSlabGroup.CHECK_EVERY
+    bad = [s for s in slabs if s.status()["errors"] & 2]
+    assert bad
+    with pytest.raises(S.SphHipError, match="lost particles"):
+        bad[0].synchronize()
+    with pytest.raises(S.SphHipError, match="lost particles"):
+        bad[0].download()
+    for s in slabs:
+        s.close()
+
+
 def test_early_exchange_reports_a_particle_it_missed(hiplib):
     """A particle deep inside a slab that jumps into the planes next to the border within one step
     was not in the early message; the next cell build must say so (error bit 8), not lose it."""

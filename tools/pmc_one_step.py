@@ -9,4 +9,6 @@ n = 4*1024*1024
 p, pos, vel, mass = scenes.dam_break(n)
 sph = S.SPH(n, p); sph.setParticles(pos, vel, mass)
 sph.setTiming(S.TIMING_OFF)
-sph.step(); sph.synchronize()
+for _ in range(3):
+    sph.step()
+sph.synchronize()
