@@ -33,13 +33,25 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10,
                     help="untimed steps first (the first ~5 steps after an upload run 5-10 %% "
                          "slower than the steady state)")
-    ap.add_argument("--particles", type=int, default=4 * 1024 * 1024,
-                    help="particles of the 1-GPU workload (default: BASELINE config C3, 4M)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = --particles per GPU in a box N times as long in z "
-                         "(one unit box per slab); strong = --particles in total, unit box")
+    ap.add_argument("--particles", type=int, default=None,
+                    help="particles in total (strong) / per GPU (weak).  Default: N = 1: 4 194 304 "
+                         "(BASELINE configs[2], C3); N > 1 strong: 16 777 216 (configs[3], C4); "
+                         "weak: 4 194 304 per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: strong (default) = --particles in total in the unit box, cut in N "
+                         "z-slabs (BASELINE configs[3]); weak = --particles per GPU in a box N "
+                         "times as long in z (one unit box per slab)")
     ap.add_argument("--no-other-scaling", action="store_true",
-                    help="N > 1: skip the shorter measurement of the other scaling mode")
+                    help="N > 1: skip the side measurement (strong: configs[4], C5 = 67 108 864 "
+                         "particles in the 8:1:1 channel; weak: the strong C4 run)")
+    ap.add_argument("--other-particles", type=int, default=None,
+                    help="N > 1: particle count of the side measurement (rehearsals)")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="N > 1, strong: skip rank 0's single-context run of the same scene "
+                         "(the denominator of strong_scaling.speedup)")
+    ap.add_argument("--no-breaking-dam", action="store_true",
+                    help="N = 1: skip the side record of the dam actually breaking (gravity + "
+                         "walls, steps 500-520)")
     ap.add_argument("--cpu-sample", type=int, default=524288,
                     help="particles in the CPU-baseline sample (0 disables); with --cpu-steps "
                          "sized for ~10 s of single-thread work")
@@ -129,17 +141,26 @@ def reference_scene(S, steps=8, n=32768):
     }
 
 
-def measured_traffic(n):
-    """HBM bytes per density+acceleration launch pair from the committed PMC passes
-    (profiles/r1_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
-    FETCH doubled as the gfx950 guide prescribes).  None when no profile matches the workload."""
+PROFILE = os.path.join(ROOT, "profiles", "r2_kernel_counters.json")
+
+
+def kernel_counters(n):
+    """What the committed counter passes say about the density + acceleration launch pair
+    (tools/profile_round.sh -> profiles/r2_kernel_counters.json): HBM bytes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as the gfx950 guide prescribes) and
+    VALU wave-instructions (SQ_INSTS_VALU).  The file carries the hash of the kernel sources it
+    was measured on: (None, reason) when that is not the code being run, or the workload differs."""
+    from smoothed_particle_hydrodynamics_amd.build import source_hash
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
-        if prof.get("particles") == n:
-            return prof["density_plus_acceleration_hbm_bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        prof = json.load(open(PROFILE))
+    except (OSError, ValueError):
+        return None, "no committed counter profile"
+    if prof.get("particles") != n:
+        return None, "the committed counters are for %s particles" % prof.get("particles")
+    if prof.get("csrc_sha16") != source_hash():
+        return None, ("the committed counters were taken on kernel sources %s, this is %s: "
+                      "re-run tools/profile_round.sh" % (prof.get("csrc_sha16"), source_hash()))
+    return prof, "profiles/r2_kernel_counters.json (kernel sources %s)" % prof["csrc_sha16"]
 
 
 def phase_split(ctx, S, step, synchronize, set_timing, phase_totals, steps=5):
@@ -183,17 +204,28 @@ def run_single(args, S, scenes, torch, local_rank):
     return p, dt, totals, covered, n, nb_mean, "1 GPU"
 
 
-def run_slabs(args, S, scenes, torch, rank, world, local_rank, scaling, steps, warmup):
-    """N > 1: one z-slab of the cell grid per GPU, neighbour exchange over RCCL (xGMI).
+C3_PARTICLES = 4 * 1024 * 1024      # BASELINE configs[2]
+C4_PARTICLES = 16 * 1024 * 1024     # BASELINE configs[3]: strong scaling over the node
+C5_PARTICLES = 64 * 1024 * 1024     # BASELINE configs[4]: 8:1:1 channel, long axis = slab axis
+C5_BOX = (1.0, 1.0, 8.0)
 
-    weak: the column is `world` unit boxes long in z and holds world x --particles (every slab
-    is the 1-GPU workload plus its halos); strong: the 1-GPU workload itself is cut in `world`
-    slabs.  Every rank derives the same cuts from the z coordinates alone and generates only
-    the particles it owns (counter-based PRNG: any subset of the scene on any rank)."""
+
+def config_name(n, box):
+    if box == (1.0, 1.0, 1.0):
+        return {262144: " (BASELINE configs[1], C2)", C3_PARTICLES: " (BASELINE configs[2], C3)",
+                C4_PARTICLES: " (BASELINE configs[3], C4)"}.get(n, "")
+    if box == C5_BOX and n == C5_PARTICLES:
+        return " (BASELINE configs[4], C5: 8:1:1 channel, long axis = slab axis)"
+    return ""
+
+
+def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, warmup):
+    """N > 1: `n` particles in `box`, one z-slab of the cell grid per GPU, neighbour exchange
+    over RCCL (xGMI).  Every rank derives the same cuts from the z coordinates alone and
+    generates only the particles it owns (counter-based PRNG: any subset of the scene on any
+    rank)."""
     import torch.distributed as dist
     from smoothed_particle_hydrodynamics_amd import slab as SL
-    n = args.particles * world if scaling == "weak" else args.particles
-    box = (1.0, 1.0, float(world)) if scaling == "weak" else (1.0, 1.0, 1.0)
     p, hi = scenes.dam_break_params(n, box)
     z = scenes.box_fill_axis(n, (0.0, 0.0, 0.0), hi, 2)
     planes = SL.plane_of(p, z)
@@ -251,9 +283,57 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, scaling, steps, w
     slab.close()
     return {"params": p, "dt": dt, "totals": totals, "covered": covered, "n": n,
             "n_rank": st["owned"], "neighbors_mean": nb_mean, "steps": steps, "box": box,
+            "ranks": dist.get_world_size(),
             "parallelism": "z-slab x%d, RCCL halo (%s)" % (
                 world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so",
                         "host": "host-staged rehearsal"}.get(mode, "torch.distributed P2P"))}
+
+
+def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup):
+    """The same scene on ONE GPU in a single context (rank 0 only, the other ranks wait): the
+    denominator of the strong-scaling speedup, measured in the same run on the same node."""
+    p, pos, vel, mass = scenes.dam_break(n, box)
+    with S.SPH(n, p, mode=S.MODE_FULL, device=local_rank) as sph:
+        sph.setParticles(pos, vel, mass)
+        del pos, vel, mass
+        sph.setTiming(S.TIMING_OFF)
+        sph.run(warmup)
+        sph.synchronize()
+        t0 = time.perf_counter()
+        sph.run(steps)
+        sph.synchronize()
+        dt = time.perf_counter() - t0
+    return dt / steps * 1e3
+
+
+def breaking_dam(S, scenes, n, device, settle=500, timed=20):
+    """Side record, never `value`: the same scene with the dam actually breaking (uniform gravity
+    and wall reflection switched on - SURVEY.md 8(f) rank 1), timed over steps settle ..
+    settle + timed, when the column has collapsed and the flow is several times denser than the
+    column at rest the headline steps (faithful to the reference, whose computeAcceleration has
+    no uniform gravity)."""
+    p, pos, vel, mass = scenes.dam_break(n)
+    p.apply_gravity = 1
+    p.apply_walls = 1
+    p.gravity[0], p.gravity[1], p.gravity[2] = 0.0, -9.81, 0.0
+    with S.SPH(n, p, mode=S.MODE_FULL, device=device) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.setTiming(S.TIMING_OFF)
+        sph.run(settle)
+        sph.synchronize()
+        t0 = time.perf_counter()
+        sph.run(timed)
+        sph.synchronize()
+        dt = (time.perf_counter() - t0) / timed
+        c = sph.getParticles().mNeighborCount
+        ts = sph.tileStats()
+    return {"workload": "the %d-particle column with apply_gravity + apply_walls, steps %d-%d" % (
+                n, settle, settle + timed),
+            "ms_per_step": dt * 1e3, "value": n / dt / 1e6, "unit": "Mparticle-steps/s",
+            "neighbors_mean": float(c.mean()), "neighbors_max": int(c.max()),
+            "particles_without_list": int((c > 254).sum()),
+            "workgroups_untiled": [int(ts["untiled_density"]), int(ts["untiled_acceleration"])],
+            "note": "side record; `value` above is the column at rest, as in the reference"}
 
 
 def main():
@@ -278,7 +358,7 @@ def main():
             raise SystemExit("libsph_hip.so is missing: run `python -c 'import __graft_entry__ as "
                              "g; g.build()'` before a multi-rank launch")
         S.build_library()
-    n = args.particles
+    strong_scaling = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -289,51 +369,92 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         dist.barrier()
-        r = run_slabs(args, S, scenes, torch, rank, world, local_rank, args.scaling, args.steps,
-                      args.warmup)
+        # strong (default): BASELINE configs[3] - 16M particles in the unit box cut in `world`
+        # slabs; weak: `world` unit boxes in a row, --particles per GPU
+        if args.scaling == "strong":
+            n = args.particles or C4_PARTICLES
+            box = (1.0, 1.0, 1.0)
+        else:
+            n = (args.particles or C3_PARTICLES) * world
+            box = (1.0, 1.0, float(world))
+        r = run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, args.steps, args.warmup)
         p, dt, totals, covered = r["params"], r["dt"], r["totals"], r["covered"]
-        n, n_rank, nb_mean, par, box = r["n"], r["n_rank"], r["neighbors_mean"], r["parallelism"], r["box"]
+        n_rank, nb_mean, par, ranks = r["n_rank"], r["neighbors_mean"], r["parallelism"], r["ranks"]
+        if args.scaling == "strong" and not args.no_one_gpu_reference:
+            # the same scene on one GPU, same run: what the N-GPU time is a speedup OF
+            one_ms = None
+            if rank == 0:
+                one_ms = one_gpu_reference(S, scenes, torch, local_rank, n, box,
+                                           max(5, args.steps // 2), min(args.warmup, 5))
+            dist.barrier()
+            if rank == 0:
+                strong_scaling = {"particles": n, "one_gpu_ms_per_step": one_ms,
+                                  "n_gpu_ms_per_step": dt / args.steps * 1e3,
+                                  "speedup": one_ms / (dt / args.steps * 1e3), "gpus": world,
+                                  "note": "rank 0 steps the whole scene in one context while "
+                                          "the other ranks wait; same node, same run"}
         other = None
         if not args.no_other_scaling:
-            # the other scaling mode, shorter, reported beside the headline (never as `value`)
-            mode = "strong" if args.scaling == "weak" else "weak"
-            o = run_slabs(args, S, scenes, torch, rank, world, local_rank, mode,
-                          max(5, args.steps // 2), min(args.warmup, 2))
-            other = {"scaling": mode, "particles": o["n"], "box": list(o["box"]),
+            # side measurement, reported beside the headline (never as `value`): with the strong
+            # headline the 64M-particle 8:1:1 channel of BASELINE configs[4] (long axis = slab
+            # axis, largest halo volume per step); with the weak headline the strong C4 run
+            if args.scaling == "strong":
+                on, obox, oname = args.other_particles or C5_PARTICLES, C5_BOX, "strong"
+            else:
+                on, obox, oname = args.other_particles or C4_PARTICLES, (1.0, 1.0, 1.0), "strong"
+            o = run_slabs(args, S, scenes, torch, rank, world, local_rank, on, obox,
+                          max(5, args.steps // 2), min(args.warmup, 3))
+            other = {"scaling": oname, "particles": o["n"], "box": list(o["box"]),
+                     "workload": "dam-break %d particles%s in a %gx%gx%g box" % (
+                         o["n"], config_name(o["n"], obox), obox[0], obox[1], obox[2]),
                      "value": o["n"] * o["steps"] / o["dt"] / 1e6, "unit": "Mparticle-steps/s",
-                     "steps": o["steps"], "ms_per_step": o["dt"] / o["steps"] * 1e3}
+                     "steps": o["steps"], "ms_per_step": o["dt"] / o["steps"] * 1e3,
+                     "neighbors_mean": o["neighbors_mean"], "ranks": o["ranks"]}
     else:
+        n = args.particles or C3_PARTICLES
+        args.particles = n
         p, dt, totals, covered, n_rank, nb_mean, par = run_single(args, S, scenes, torch,
                                                                   local_rank)
-        box, other = (1.0, 1.0, 1.0), None
+        box, other, ranks = (1.0, 1.0, 1.0), None, 1
 
     if rank == 0:
         # density+acceleration pair: HIP events on the context's stream over the timed steps
         df_ms = totals["pair_ms"]
         achieved = DENSITY_FORCE_BYTES * n_rank / (df_ms * 1e-3) / 1e9
+        prof, prof_note = kernel_counters(n) if world == 1 else (None, "1-GPU profile only")
+        valu = None
+        if prof is not None and prof.get("valu_wave_instructions_per_launch_pair"):
+            # VALU issue: the SQ books one quad-cycle (4 cycles) of a SIMD per VALU wave-instruction
+            # (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in the committed passes); the chip has
+            # 256 CUs x 4 SIMDs; elapsed = the pair's live duration at the nominal 2.4 GHz
+            insts = prof["valu_wave_instructions_per_launch_pair"]
+            valu = {"wave_instructions_per_launch_pair": insts, "cycles_per_wave_instruction": 4,
+                    "simds": 1024, "clock_ghz": 2.4,
+                    "frac": insts * 4.0 / (1024 * df_ms * 1e-3 * 2.4e9),
+                    "note": "share of the SIMDs' issue cycles the pair's VALU instructions book: "
+                            "this is the bound that is real for the pass (DESIGN.md 3.2)"}
+        scaling = args.scaling if world > 1 else "weak"
         line = {
-            "metric": "Mparticle-steps/sec (whole node), dam-break",
+            "metric": "Mparticle-steps/sec (whole node), dam-break" + (
+                "" if world == 1 else ", %s scaling, %d particles in total on %d GPUs" % (
+                    scaling, n, world)),
             "value": n * args.steps / dt / 1e6,
             "unit": "Mparticle-steps/s",
             "n_gpus": world,
+            "ranks": ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "dam-break %d particles%s in a %gx%gx%g box, fp32, FULL neighbour "
                             "mode, cell grid rebuilt every step" % (
-                                n, {262144: " (BASELINE configs[1], C2)",
-                                    4194304: " (BASELINE configs[2], C3)",
-                                    16777216: " (BASELINE configs[3], C4)"}.get(n, "")
-                                if world == 1 or args.scaling == "strong" else
-                                " = %d x the 1-GPU workload%s, one unit box per slab along z" % (
-                                    world, " (BASELINE configs[2], C3)"
-                                    if args.particles == 4194304 else ""),
+                                n, config_name(n, box) if world == 1 or scaling == "strong" else
+                                " = %d x %d, one unit box per slab along z" % (world, n // world),
                                 box[0], box[1], box[2]),
                 "particles": n,
                 "particles_per_gpu": n // world,
@@ -354,8 +475,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n) if world == 1 else None,
-                "traffic_unit": "bytes per launch pair (profiles/r1_hbm_traffic.json)",
+                "traffic": prof["density_plus_acceleration_hbm_bytes"] if prof else None,
+                "traffic_unit": "bytes per launch pair",
+                "traffic_source": prof_note,
+                "valu": valu,
                 "bytes_per_particle": DENSITY_FORCE_BYTES,
                 "particles_per_launch": n_rank,
                 "ms_per_launch_pair": df_ms,
@@ -363,8 +486,12 @@ def main():
                         "64 B/particle compulsory-traffic figure of SURVEY.md 8(d)",
             },
         }
+        if strong_scaling is not None:
+            line["strong_scaling"] = strong_scaling
         if other is not None:
             line["other_scaling"] = other
+        if world == 1 and not args.no_breaking_dam:
+            line["breaking_dam"] = breaking_dam(S, scenes, n, local_rank)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
             ref_scene = reference_scene(S)

@@ -25,6 +25,20 @@ def library_path():
     return os.environ.get("SPH_HIP_LIBRARY") or os.path.join(HERE, "libsph_hip.so")
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the C header: what a committed
+    counter profile (profiles/) is stamped with, so that bench.py can tell whether it still
+    describes the code being run."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        path = os.path.normpath(os.path.join(CSRC, name))
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(out):
     if not os.path.exists(out):
         return True

@@ -483,6 +483,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          }
       }
    }
+   // An odd count leaves the second half of the last word unwritten: zero it (a valid tile index).
+   // The acceleration pass gathers by every entry of the words it fetches before it looks at the
+   // count, and what an earlier step left there need not be an index of this step's tile.
+   if ((count & 1) && count < NLIST_CAP) my_entries[half] = (uint16_t)0;
    // A particle with more neighbours than its list holds (a scene many times denser than the
    // benchmark's) goes without a list: its lane walks its candidate ranges in the tile one by one
    // here - canonical order, small code - and again in the acceleration pass, which recognises it
@@ -578,6 +582,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                }
             }
          }
+         if (kept & 1) my_entries[(kept >> 1) * (2 * TILE_THREADS) + 1] = (uint16_t)0;
          count = kept;
       }
    }

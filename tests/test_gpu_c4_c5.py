@@ -1,0 +1,122 @@
+"""GPU, BASELINE configs[3] and [4] at full size on ONE device.
+
+C4 = 16 777 216-particle dam-break in the unit box, cut in 8 z-slabs; C5 = 67 108 864 particles
+in the 8:1:1 channel whose long axis is the slab axis, 8 slabs.  An 8-GPU node runs one slab per
+GPU over RCCL; here the eight slab contexts live on the one GPU of the test box and hand their
+messages over by pointer (LocalSlabGroup) - kernels, message format, ghost/migrant protocol, the
+early exchange with its border work on a second, high-priority stream: all exactly those of the
+distributed run, only the transport differs (covered under gloo in test_slab_cpu.py).
+
+The oracle cannot step these sizes, so parity is shown as in test_gpu_full_size.py:
+  * 8 slabs == a single context, bit for bit, for every particle (SHA-256 of every array) -
+    the single context being the configuration whose window is checked against the oracle;
+  * C4: an EXACT oracle check on the particles of a thin z-window that straddles a slab cut;
+  * size-independent properties: every id owned exactly once, counts even (symmetric relation),
+    ~32 neighbours, no error bit on any slab.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import to_oracle_params
+
+pytestmark = pytest.mark.gpu
+
+C4 = 16 * 1024 * 1024
+C5 = 64 * 1024 * 1024
+C5_BOX = (1.0, 1.0, 8.0)
+WORLD = 8
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_eight_slabs(p, pos, vel, mass, steps):
+    """`steps` steps as 8 logical slabs: early exchange, border work on a second stream."""
+    import torch
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    z = pos.reshape(-1, 3)[:, 2]
+    cuts = SL.plan_cuts(p, z, WORLD)
+    hist = np.bincount(SL.plane_of(p, z), minlength=p.full_cells_z)
+    stream = torch.cuda.Stream()
+    slabs = []
+    for r in range(WORLD):
+        cap, msg = SL.slab_capacities(hist, cuts, r, slack=1.5)
+        s = SL.HipSlab(p, cuts[r], cuts[r + 1], cap, msg, device=0, has_left=r > 0,
+                       has_right=r + 1 < WORLD, stream=stream)
+        s.upload(*SL.split_scene(p, cuts, r, pos, vel, mass), all_masses_equal=True)
+        slabs.append(s)
+    group = SL.LocalSlabGroup(slabs, overlap=True, exchange_stream=torch.cuda.Stream(priority=-1))
+    for _ in range(steps):
+        group.step()
+    got = group.gather(mass.size)
+    status = [s.status() for s in slabs]
+    for s in slabs:
+        s.close()
+    return got, status, cuts
+
+
+def run_single(p, pos, vel, mass, steps):
+    import smoothed_particle_hydrodynamics_amd as S
+    with S.SPH(mass.size, p) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.run(steps)
+        part = sph.getParticles()
+        return dict(pos=part.mPosition.copy(), vel=part.mVelocity.copy(), rho=part.mDensity.copy(),
+                    acc=part.mAcceleration.copy(), ncount=part.mNeighborCount.copy())
+
+
+def check_properties(got, status, n):
+    assert (got["owner"] >= 0).all(), "a particle belongs to no slab"
+    assert sum(s["owned"] for s in status) == n
+    assert all(s["errors"] == 0 for s in status), [s["errors"] for s in status]
+    assert got["ncount"].sum() % 2 == 0                  # d2(i,j) == d2(j,i): symmetric relation
+    assert 30.0 < got["ncount"].mean() < 32.5            # ~32 by construction of h
+    assert np.isfinite(got["acc"]).all() and np.isfinite(got["rho"]).all()
+
+
+def test_c4_eight_slabs_equal_single_context_and_oracle_window(oracle, hiplib):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(C4)
+    got, status, cuts = run_eight_slabs(p, pos, vel, mass, steps=1)
+    check_properties(got, status, C4)
+    one = run_single(p, pos, vel, mass, steps=1)
+    for k in ("pos", "vel", "rho", "acc", "ncount"):
+        assert sha(got[k]) == sha(one[k]), k
+    # exact oracle check on a z-window around the cut between slabs 3 and 4: its particles and
+    # their neighbours (2h + margin) go to the oracle with the same parameters and grid
+    h = np.float32(p.h)
+    z = pos.reshape(-1, 3)[:, 2]
+    cell = np.float32(1.0) / np.float32(p.full_cell_inv)
+    zc = np.float32(cuts[4]) * cell
+    z0, z1 = zc - np.float32(0.006), zc + np.float32(0.006)
+    margin = np.float32(2.0) * h * np.float32(1.05) + np.float32(2.0) * cell
+    sub = np.nonzero((z >= z0 - margin) & (z < z1 + margin))[0]          # ascending ids
+    inner = (z[sub] >= z0) & (z[sub] < z1)
+    assert inner.sum() > 100000 and sub.size < 900000
+    spos = np.ascontiguousarray(pos.reshape(-1, 3)[sub]).reshape(-1)
+    svel = np.ascontiguousarray(vel.reshape(-1, 3)[sub]).reshape(-1)
+    ref = oracle.step(to_oracle_params(p), spos, svel, np.ascontiguousarray(mass[sub]), mode="full")
+    ids = sub[inner]
+    owners = set(got["owner"][ids].tolist())
+    assert owners == {3, 4}, owners                       # the window straddles the cut
+    assert np.array_equal(got["ncount"][ids], ref["ncount"][inner])
+    assert np.array_equal(got["rho"][ids], ref["rho"][inner])
+    assert np.array_equal(got["acc"].reshape(-1, 3)[ids], ref["acc"].reshape(-1, 3)[inner])
+    assert np.array_equal(got["pos"].reshape(-1, 3)[ids], spos.reshape(-1, 3)[inner])
+    assert np.array_equal(got["vel"].reshape(-1, 3)[ids], svel.reshape(-1, 3)[inner])
+
+
+def test_c5_channel_eight_slabs_two_steps_equal_single_context(hiplib):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(C5, box=C5_BOX)
+    assert p.full_cells_z > 7 * p.full_cells_x            # the long axis is the slab axis
+    got, status, cuts = run_eight_slabs(p, pos, vel, mass, steps=2)
+    check_properties(got, status, C5)
+    want = {k: sha(v) for k, v in got.items() if k != "owner"}
+    del got
+    one = run_single(p, pos, vel, mass, steps=2)
+    for k in ("pos", "vel", "rho", "acc", "ncount"):
+        assert sha(one[k]) == want[k], k

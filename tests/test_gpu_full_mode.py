@@ -344,3 +344,31 @@ def test_pair_loop_square_root_equals_sqrtf_for_every_float(hiplib):
     bad, first = C.c_uint64(123), C.c_uint32(0)
     assert hiplib.sph_hip_selftest_sqrt(0, C.byref(bad), C.byref(first)) == 0
     assert bad.value == 0, "%d inputs differ, the smallest has bits 0x%08x" % (bad.value, first.value)
+
+
+def test_full_context_reuse_with_a_different_scene(oracle, hiplib):
+    """One context, three scenes one after the other (dense block, then the thinner dam-break,
+    then a block elsewhere): the neighbour lists, tile descriptors and per-workgroup flags a scene
+    leaves in device memory must never reach the next one's sums.  (An odd-length list used to
+    leave the second half of its last word as the previous scene wrote it, and the acceleration
+    pass gathers by every entry of a fetched word before it looks at the count: a stale entry is
+    no index of the new tile - an out-of-bounds gather once the dam actually breaks.)"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    n = 40000
+    cases = [scenes.dense_block(n, lo=(1.0, 1.0, 1.0), hi=(1.9, 1.9, 1.9), speed=30.0),
+             scenes.dense_block(n, lo=(0.2, 0.3, 0.1), hi=(4.0, 4.5, 5.0), seed=3, speed=30.0),
+             scenes.dense_block(n, lo=(3.0, 0.1, 3.5), hi=(3.8, 1.2, 4.6), seed=5, speed=30.0)]
+    p = cases[0][0]
+    with S.SPH(n, p, mode=S.MODE_FULL) as sph:
+        for k, (pk, pos, vel, mass) in enumerate(cases):
+            assert bytes(pk) == bytes(p)
+            opos, ovel = pos.copy(), vel.copy()
+            sph.setParticles(pos, vel, mass)
+            for s in range(4):
+                sph.step()
+                ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+            part = sph.getParticles()
+            check_state(part, ref, "scene %d" % k)
+            assert np.array_equal(part.mPosition, opos)
+            assert np.array_equal(part.mVelocity, ovel)
