@@ -131,6 +131,26 @@ int sph_hip_upload(sph_hip_context* ctx, int n, const float* pos, const float* v
 int sph_hip_download(sph_hip_context* ctx, float* pos, float* vel, float* density, float* acc,
                      int32_t* neighbor_count);
 
+/* The same mirror without stopping the solver thread - what the reference's GUI gets when it
+ * reads SPH::getParticles() / getGrid() at 60 Hz from another thread, without locks
+ * (reference src/visualization.cpp:144-158, 178-193).
+ *   sph_hip_download_async  enqueues, behind the work queued so far, a snapshot of the
+ *       per-particle arrays (any pointer may be NULL) and of the per-voxel occupancy on the
+ *       REFERENCE voxel grid (cells_x*cells_y*cells_z ints, edge mCellSize - in FULL mode too),
+ *       and their copy to the host on a separate low-priority stream; returns at once.  The
+ *       later steps' kernels do not wait for the copy.  *started = 0 (nothing done) while the
+ *       previous request is still on its way: a mirror is a picture, not a queue.
+ *   sph_hip_download_done   1 = the last request has arrived in the host arrays, 0 = not yet
+ *       (wait != 0: blocks until it has).  Negative = error.
+ *   sph_hip_host_register   page-locks host memory (e.g. the storage of Particle's vectors) so
+ *       that the copy really is asynchronous; pageable memory works, slower and less overlapped.
+ * Double-buffer on the host: request into the back set, swap when done (integration/). */
+int sph_hip_download_async(sph_hip_context* ctx, float* pos, float* vel, float* density, float* acc,
+                           int32_t* neighbor_count, int32_t* voxel_counts, int* started);
+int sph_hip_download_done(sph_hip_context* ctx, int wait);
+int sph_hip_host_register(void* ptr, size_t bytes);
+int sph_hip_host_unregister(void* ptr);
+
 int sph_hip_particle_count(const sph_hip_context* ctx);
 
 /* ---- the step -------------------------------------------------------------------------- */

@@ -10,12 +10,21 @@
 #undef protected
 #include "particle.h"
 
+// free functions of sph_dropin.cpp for hosts that read the mirror right after stepping
+void sph_dropin_sync_mirror();
+long long sph_dropin_steps_returned_before_copy();
+
 int main(int argc, char** argv)
 {
    const int steps = argc > 1 ? atoi(argv[1]) : 1;
    const char* out = argc > 2 ? argv[2] : "dropin_state.bin";
    SPH sph;
    for (int s = 0; s < steps; s++) sph.step();
+   // step() returns while the snapshot of its state is still on its way to the host mirror (the
+   // GUI reads whatever complete mirror is current); a program that wants the LAST step waits
+   printf("dropin: %lld of %d step() calls returned before their snapshot had arrived\n",
+          sph_dropin_steps_returned_before_copy(), steps);
+   sph_dropin_sync_mirror();
    Particle* p = sph.getParticles();
    const int n = sph.getParticleCount();
    FILE* f = fopen(out, "wb");

@@ -9,10 +9,19 @@
 // Every member keeps its meaning (reference src/sph.h:20-139):
 //   * the constructor derives the constants through sph_hip_params_default (same arithmetic as
 //     src/sph.cpp:46-98), builds the default scene and uploads it;
-//   * step() runs the five phases on the GPU, refreshes the host mirrors that the GUI reads
-//     without locks (Particle arrays, per-voxel QList sizes) and emits the same two signals;
-//   * the six setters store the value and hand the parameter block to the library, which
-//     applies it at the next phase.
+//   * step() runs the five phases on the GPU and emits the same two signals.  The host mirrors
+//     the GUI reads at frame rate without locks (Particle arrays through getParticles(),
+//     per-voxel QList sizes through getGrid(); reference src/visualization.cpp:144-158, 178-193)
+//     are DOUBLE-BUFFERED: step() asks the library for an asynchronous snapshot into the back
+//     `Particle` (page-locked, copied on a separate stream: sph_hip_download_async) and returns
+//     without waiting for it; a later step() finds it complete and swaps it in.  The solver never
+//     stalls on PCIe, the GUI always sees one complete state at most a frame or two old - in both
+//     neighbour modes (the occupancy comes on the reference's voxel grid in FULL mode too).
+//     SPH_DROPIN_SYNC_MIRROR=1 (or sph_dropin_sync_mirror() before reading) gives the blocking
+//     behaviour: the mirror then shows the step just taken;
+//   * the six setters are called from the GUI thread (reference src/sphconfig.cpp:89-94) while
+//     the solver thread steps: they write the parameter block under a mutex, step() takes a copy
+//     under the same mutex and hands it to the library, which applies it at that step.
 // The per-particle protected methods (findNeighbors(i, ...), computeDensity(i, ...), ...) have
 // no per-particle GPU meaning; they stay as no-ops because nothing outside step() calls them.
 #include "sph.h"
@@ -26,6 +35,8 @@
 
 #include <fstream>
 #include <iostream>
+#include <mutex>
+#include <vector>
 
 #include "sph_hip.h"
 
@@ -35,8 +46,24 @@
 
 namespace {
 sph_hip_context* g_ctx = nullptr; // one solver per process, like the reference's single SPH object
-sph_hip_params g_prm;
+sph_hip_params g_prm;             // written by the GUI's setters, read by step(): under g_prm_mutex
+std::mutex g_prm_mutex;
 int g_mode = SPH_HIP_MODE_REF;    // SPH_HIP_MODE_FULL for complete neighbourhoods
+
+// The two host mirrors: `front` is what getParticles() hands out, `back` is being filled by the
+// library (or waits to be).  Both are the reference's own `Particle` (std::vector storage,
+// page-locked once so that the copy into it is a DMA the solver thread does not wait for).
+Particle* g_back = nullptr;
+std::vector<int32_t> g_counts_front, g_counts_back;   // per-voxel occupancy on the reference grid
+bool g_copy_in_flight = false;
+bool g_sync_mirror = false;       // SPH_DROPIN_SYNC_MIRROR: wait for every step's snapshot
+long long g_steps_taken = 0, g_step_mirrored = -1, g_step_in_flight = -1;
+long long g_returned_before_copy = 0;   // step() calls that returned while their snapshot was still travelling
+// where the solver object keeps what the mirror swap touches (protected members; noted by the
+// constructor so that the free function below can publish a mirror too)
+Particle** g_front_slot = nullptr;
+QList<uint32_t>* g_grid = nullptr;
+int g_cells = 0;
 
 void check(int rc, const char* what)
 {
@@ -78,7 +105,9 @@ SPH::SPH()
    mExamineCount = g_prm.examine_count;
 
    mSrcParticles = new Particle(mParticleCount);
-   for (int i = 0; i < mParticleCount; i++) mSrcParticles->mMass[i] = 1.0f;
+   g_back = new Particle(mParticleCount);
+   for (int i = 0; i < mParticleCount; i++) mSrcParticles->mMass[i] = g_back->mMass[i] = 1.0f;
+   g_sync_mirror = getenv("SPH_DROPIN_SYNC_MIRROR") != nullptr;
    mVoxelIds = new int[mParticleCount];
    mVoxelCoords = new vec3i[mParticleCount];
    mGrid = new QList<uint32_t>[mGridCellCount];
@@ -90,7 +119,74 @@ SPH::SPH()
    check(sph_hip_upload(g_ctx, mParticleCount, mSrcParticles->mPosition.data(),
                         mSrcParticles->mVelocity.data(), mSrcParticles->mMass.data()),
          "sph_hip_upload");
+   // before the first snapshot arrives the GUI sees the initial condition in both mirrors
+   g_back->mPosition = mSrcParticles->mPosition;
+   g_back->mVelocity = mSrcParticles->mVelocity;
+   g_counts_front.assign(mGridCellCount, 0);
+   g_counts_back.assign(mGridCellCount, 0);
+   for (Particle* p : {mSrcParticles, g_back}) {   // page-lock the mirrors (a failure only costs overlap)
+      (void)sph_hip_host_register(p->mPosition.data(), p->mPosition.size() * sizeof(float));
+      (void)sph_hip_host_register(p->mVelocity.data(), p->mVelocity.size() * sizeof(float));
+      (void)sph_hip_host_register(p->mDensity.data(), p->mDensity.size() * sizeof(float));
+      (void)sph_hip_host_register(p->mAcceleration.data(), p->mAcceleration.size() * sizeof(float));
+      (void)sph_hip_host_register(p->mNeighborCount.data(), p->mNeighborCount.size() * sizeof(int));
+   }
+   (void)sph_hip_host_register(g_counts_front.data(), g_counts_front.size() * sizeof(int32_t));
+   (void)sph_hip_host_register(g_counts_back.data(), g_counts_back.size() * sizeof(int32_t));
+   g_front_slot = &mSrcParticles;
+   g_grid = mGrid;
+   g_cells = mGridCellCount;
 }
+
+// The snapshot that was travelling has arrived: it becomes what getParticles() / getGrid() show.
+// The GUI fetches the pointer every frame (src/visualization.cpp:145, 178); a frame that still
+// reads the old front buffer reads a complete older state - the buffer is not written again
+// before the NEXT swap.
+static void publish_mirror()
+{
+   Particle* filled = g_back;
+   g_back = *g_front_slot;
+   *g_front_slot = filled;
+   g_counts_front.swap(g_counts_back);
+   for (int c = 0; c < g_cells; c++) {   // only count() is ever read from these lists
+      QList<uint32_t>& l = g_grid[c];
+      const int want = g_counts_front[c];
+      if (l.size() == want) continue;
+      while (l.size() > want) l.removeLast();
+      while (l.size() < want) l.append(0u);
+   }
+   g_step_mirrored = g_step_in_flight;
+   g_copy_in_flight = false;
+}
+
+static void request_mirror()
+{
+   Particle* p = g_back;
+   int started = 0;
+   check(sph_hip_download_async(g_ctx, p->mPosition.data(), p->mVelocity.data(), p->mDensity.data(),
+                                p->mAcceleration.data(), p->mNeighborCount.data(),
+                                g_counts_back.data(), &started), "sph_hip_download_async");
+   if (started) {
+      g_copy_in_flight = true;
+      g_step_in_flight = g_steps_taken;
+   }
+}
+
+// Free functions for hosts that need the mirror to show the LAST step (file writers, tests);
+// the GUI never calls them.  Declared by their users (the reference's headers stay unchanged).
+void sph_dropin_sync_mirror()
+{
+   if (g_copy_in_flight) {
+      if (sph_hip_download_done(g_ctx, 1) < 0) check(SPH_HIP_ERR_DEVICE, "sph_hip_download_done");
+      publish_mirror();
+   }
+   if (g_step_mirrored != g_steps_taken) {   // the snapshot that arrived was of an earlier step
+      request_mirror();
+      if (sph_hip_download_done(g_ctx, 1) < 0) check(SPH_HIP_ERR_DEVICE, "sph_hip_download_done");
+      publish_mirror();
+   }
+}
+long long sph_dropin_steps_returned_before_copy() { return g_returned_before_copy; }
 
 SPH::~SPH()
 {
@@ -134,9 +230,18 @@ void SPH::run()
 
 void SPH::step()
 {
-   // parameters edited by the GUI since the last step (SphConfig::writeValuesToSimulation)
-   check(sph_hip_set_params(g_ctx, &g_prm), "sph_hip_set_params");
+   // parameters edited by the GUI since the last step (SphConfig::writeValuesToSimulation runs on
+   // the GUI thread): one consistent copy per step
+   sph_hip_params prm;
+   {
+      std::lock_guard<std::mutex> lock(g_prm_mutex);
+      prm = g_prm;
+   }
+   check(sph_hip_set_params(g_ctx, &prm), "sph_hip_set_params");
+   // a snapshot requested by an earlier step has arrived meanwhile: show it
+   if (g_copy_in_flight && sph_hip_download_done(g_ctx, 0) == 1) publish_mirror();
    check(sph_hip_step(g_ctx), "sph_hip_step");
+   g_steps_taken++;
 
    float ms[6];
    check(sph_hip_get_timings(g_ctx, ms), "sph_hip_get_timings");
@@ -146,19 +251,12 @@ void SPH::step()
    check(sph_hip_get_energy(g_ctx, &mKineticEnergyTotal, &mPotentialEnergyTotal),
          "sph_hip_get_energy");
 
-   // host mirrors read by Visualization / SphConfig (src/visualization.cpp:144-158, 178-193)
-   Particle* p = mSrcParticles;
-   check(sph_hip_download(g_ctx, p->mPosition.data(), p->mVelocity.data(), p->mDensity.data(),
-                          p->mAcceleration.data(), p->mNeighborCount.data()), "sph_hip_download");
-   if (g_mode == SPH_HIP_MODE_REF) {
-      static std::vector<int32_t> counts;
-      counts.resize(mGridCellCount);
-      check(sph_hip_download_grid_counts(g_ctx, counts.data()), "sph_hip_download_grid_counts");
-      for (int c = 0; c < mGridCellCount; c++) {   // only count() is ever read from these lists
-         QList<uint32_t>& l = mGrid[c];
-         while (l.size() > counts[c]) l.removeLast();
-         while (l.size() < counts[c]) l.append(0u);
-      }
+   // ask for this step's state into the back mirror; the copy travels while the next steps run
+   if (!g_copy_in_flight) request_mirror();
+   if (g_sync_mirror) {
+      sph_dropin_sync_mirror();
+   } else if (g_copy_in_flight && sph_hip_download_done(g_ctx, 0) == 0) {
+      g_returned_before_copy++;
    }
    emit updateElapsed(timeVoxelize, timeFindNeighbors, timeComputeDensity, timeComputePressure,
                       timeComputeAcceleration, timeIntegrate);
@@ -219,20 +317,38 @@ QList<uint32_t>* SPH::getGrid() { return mGrid; }
 vec3 SPH::getGravity() const { return mGravity; }
 void SPH::setGravity(const vec3& g)
 {
+   std::lock_guard<std::mutex> lock(g_prm_mutex);
    mGravity = g;
    g_prm.gravity[0] = g.x; g_prm.gravity[1] = g.y; g_prm.gravity[2] = g.z;
 }
 float SPH::getCflLimit() const { return mCflLimit; }
 void SPH::setCflLimit(float v)
 {
+   std::lock_guard<std::mutex> lock(g_prm_mutex);
    mCflLimit = v; mCflLimit2 = v * v;
    g_prm.cfl_limit = mCflLimit; g_prm.cfl_limit2 = mCflLimit2;
 }
 float SPH::getDamping() const { return mDamping; }
-void SPH::setDamping(float v) { mDamping = v; g_prm.damping = v; }
+void SPH::setDamping(float v)
+{
+   std::lock_guard<std::mutex> lock(g_prm_mutex);
+   mDamping = v; g_prm.damping = v;
+}
 float SPH::getTimeStep() const { return mTimeStep; }
-void SPH::setTimeStep(float v) { mTimeStep = v; g_prm.time_step = v; }
+void SPH::setTimeStep(float v)
+{
+   std::lock_guard<std::mutex> lock(g_prm_mutex);
+   mTimeStep = v; g_prm.time_step = v;
+}
 float SPH::getViscosityScalar() const { return mViscosityScalar; }
-void SPH::setViscosityScalar(float v) { mViscosityScalar = v; g_prm.viscosity = v; }
+void SPH::setViscosityScalar(float v)
+{
+   std::lock_guard<std::mutex> lock(g_prm_mutex);
+   mViscosityScalar = v; g_prm.viscosity = v;
+}
 float SPH::getStiffness() const { return mStiffness; }
-void SPH::setStiffness(float v) { mStiffness = v; g_prm.stiffness = v; }
+void SPH::setStiffness(float v)
+{
+   std::lock_guard<std::mutex> lock(g_prm_mutex);
+   mStiffness = v; g_prm.stiffness = v;
+}

@@ -236,6 +236,19 @@ k_export(const float4* __restrict__ posm, const float4* __restrict__ velp,
    if (ocount) ocount[id] = ncount[p];
 }
 
+// per-voxel occupancy on the REFERENCE voxel grid (edge mCellSize = 2h, reference
+// src/sph.cpp:438-481) whatever grid the context sorts by: what getGrid()[i].count() readers get
+__global__ void __launch_bounds__(256)
+k_voxel_counts(const float4* __restrict__ posm, const int32_t* __restrict__ meta, float inv, int nx,
+               int ny, int nz, int32_t* __restrict__ counts)
+{
+   const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_OWN_END]) return;
+   const float4 x = posm[p];
+   const int cx = cell_coord(x.x, inv, nx), cy = cell_coord(x.y, inv, ny), cz = cell_coord(x.z, inv, nz);
+   atomicAdd(&counts[(cz * ny + cy) * nx + cx], 1);
+}
+
 // ---- neighbour statistics (reference src/sph.cpp:204-232) -----------------------------------------
 // out: [0] = sum low 32, [1] = sum high 32 (as one 64-bit add), [2] = max, [3] = min (from 34)
 __global__ void __launch_bounds__(RED_THREADS)

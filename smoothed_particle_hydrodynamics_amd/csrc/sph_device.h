@@ -188,6 +188,13 @@ struct sph_hip_context {
    hipEvent_t watch_event = nullptr;  // behind the last requested copy of the error word
    int watch_pending = 0;
 
+   // asynchronous host mirror (sph_hip_download_async): its own device staging, copy stream and events
+   float* mirror_stage = nullptr;     // capacity * 11 floats + voxel counts
+   hipStream_t copy_stream = nullptr;
+   hipEvent_t ev_exported = nullptr;  // compute stream: the mirror staging is complete
+   hipEvent_t ev_copied = nullptr;    // copy stream: it has reached the host
+   int mirror_busy = 0;               // a copy has been started and not yet been seen complete
+
    // staging for host <-> device in the reference's interleaved layouts
    float* stage = nullptr; // capacity * 11 floats
 };

@@ -115,6 +115,11 @@ void free_all(sph_hip_context* ctx)
    if (ctx->ev_density) (void)hipEventDestroy(ctx->ev_density);
    if (ctx->ev_border) (void)hipEventDestroy(ctx->ev_border);
    if (ctx->tile_feedback) (void)hipHostFree(ctx->tile_feedback);
+   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+   if (ctx->mirror_stage) (void)hipFree(ctx->mirror_stage);
+   if (ctx->ev_exported) (void)hipEventDestroy(ctx->ev_exported);
+   if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
+   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
    if (ctx->err_watch) (void)hipHostFree((void*)ctx->err_watch);
    if (ctx->watch_event) (void)hipEventDestroy(ctx->watch_event);
    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1044,6 +1049,113 @@ int sph_hip_download(sph_hip_context* ctx, float* pos, float* vel, float* densit
       return SPH_HIP_ERR_INVALID;
    }
    return download_impl(ctx, 0, ctx->n_owned, nullptr, pos, vel, density, acc, neighbor_count);
+}
+
+// ---- asynchronous host mirror ---------------------------------------------------------------
+
+int sph_hip_host_register(void* ptr, size_t bytes)
+{
+   if (!ptr || bytes == 0) return SPH_HIP_ERR_INVALID;
+   const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+   if (e != hipSuccess) {
+      (void)hipGetLastError();
+      g_create_error = std::string("sph_hip_host_register: ") + hipGetErrorString(e);
+      return SPH_HIP_ERR_DEVICE;
+   }
+   return SPH_HIP_OK;
+}
+
+int sph_hip_host_unregister(void* ptr)
+{
+   if (!ptr) return SPH_HIP_ERR_INVALID;
+   if (hipHostUnregister(ptr) != hipSuccess) {
+      (void)hipGetLastError();
+      return SPH_HIP_ERR_DEVICE;
+   }
+   return SPH_HIP_OK;
+}
+
+int sph_hip_download_done(sph_hip_context* ctx, int wait)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (!ctx->mirror_busy) return 1;
+   if (wait) {
+      SPH_TRY(hipEventSynchronize(ctx->ev_copied));
+   } else {
+      const hipError_t e = hipEventQuery(ctx->ev_copied);
+      if (e == hipErrorNotReady) {
+         (void)hipGetLastError();
+         return 0;
+      }
+      SPH_TRY(e);
+   }
+   ctx->mirror_busy = 0;
+   return 1;
+}
+
+int sph_hip_download_async(sph_hip_context* ctx, float* pos, float* vel, float* density, float* acc,
+                           int32_t* neighbor_count, int32_t* voxel_counts, int* started)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (started) *started = 0;
+   if (!(ctx->plane_lo == 0 && ctx->plane_hi == ctx->grid.nz_global)) {
+      ctx->err = "sph_hip_download_async: whole-grid contexts only";
+      return SPH_HIP_ERR_INVALID;
+   }
+   // the previous mirror is still on its way: this request is dropped (a mirror is a picture of
+   // the latest state, not a queue) - its staging must not be overwritten under the copy
+   rc = sph_hip_download_done(ctx, 0);
+   if (rc < 0) return rc;
+   if (rc == 0) return SPH_HIP_OK;
+   const int n = ctx->n_owned;
+   const sph_hip_params& prm = ctx->prm;
+   const size_t cells = (size_t)prm.cells_x * prm.cells_y * prm.cells_z;
+   if (!ctx->mirror_stage) {
+      SPH_TRY(hipMalloc((void**)&ctx->mirror_stage, sizeof(float) * ((size_t)ctx->capacity * 11 + cells)));
+      int least = 0, greatest = 0;
+      SPH_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      SPH_TRY(hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, least));
+      SPH_TRY(hipEventCreateWithFlags(&ctx->ev_exported, hipEventDisableTiming));
+      SPH_TRY(hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming));
+   }
+   float* spos = ctx->mirror_stage;
+   float* svel = spos + 3 * (size_t)n;
+   float* srho = svel + 3 * (size_t)n;
+   float* sacc = srho + (size_t)n;
+   int32_t* scnt = reinterpret_cast<int32_t*>(sacc + 3 * (size_t)n);
+   int32_t* svox = reinterpret_cast<int32_t*>(ctx->mirror_stage + (size_t)ctx->capacity * 11);
+   hipStream_t st = ctx->stream;
+   if (n > 0)
+      hipLaunchKernelGGL(k_export, dim3(div_up(ctx->n, 256)), dim3(256), 0, st, ctx->posm[ctx->cur],
+                         ctx->velp[ctx->cur], ctx->rho, ctx->acc, ctx->ncount, ctx->meta, 0,
+                         pos ? spos : nullptr, vel ? svel : nullptr, density ? srho : nullptr,
+                         acc ? sacc : nullptr, neighbor_count ? scnt : nullptr, (uint32_t*)nullptr);
+   if (voxel_counts) {
+      SPH_TRY(hipMemsetAsync(svox, 0, cells * sizeof(int32_t), st));
+      if (n > 0)
+         hipLaunchKernelGGL(k_voxel_counts, dim3(div_up(ctx->n, 256)), dim3(256), 0, st,
+                            ctx->posm[ctx->cur], ctx->meta, prm.htimes2inv, prm.cells_x, prm.cells_y,
+                            prm.cells_z, svox);
+   }
+   SPH_TRY(hipGetLastError());
+   // the copies run on their own low-priority stream: the next steps' kernels do not wait for PCIe
+   SPH_TRY(hipEventRecord(ctx->ev_exported, st));
+   hipStream_t cs = ctx->copy_stream;
+   SPH_TRY(hipStreamWaitEvent(cs, ctx->ev_exported, 0));
+   if (pos) SPH_TRY(hipMemcpyAsync(pos, spos, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, cs));
+   if (vel) SPH_TRY(hipMemcpyAsync(vel, svel, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, cs));
+   if (density) SPH_TRY(hipMemcpyAsync(density, srho, sizeof(float) * n, hipMemcpyDeviceToHost, cs));
+   if (acc) SPH_TRY(hipMemcpyAsync(acc, sacc, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, cs));
+   if (neighbor_count)
+      SPH_TRY(hipMemcpyAsync(neighbor_count, scnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, cs));
+   if (voxel_counts)
+      SPH_TRY(hipMemcpyAsync(voxel_counts, svox, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, cs));
+   SPH_TRY(hipEventRecord(ctx->ev_copied, cs));
+   ctx->mirror_busy = 1;
+   if (started) *started = 1;
+   return SPH_HIP_OK;
 }
 
 int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uint32_t* ids,

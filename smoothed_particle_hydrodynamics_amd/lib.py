@@ -64,6 +64,11 @@ PROTOTYPES = {
     "sph_hip_upload": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sph_hip_download": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sph_hip_particle_count": (C.c_int, [_ctx]),
+    "sph_hip_download_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, _P(C.c_int)]),
+    "sph_hip_download_done": (C.c_int, [_ctx, C.c_int]),
+    "sph_hip_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "sph_hip_host_unregister": (C.c_int, [C.c_void_p]),
     "sph_hip_step": (C.c_int, [_ctx]),
     "sph_hip_run": (C.c_int, [_ctx, C.c_int]),
     "sph_hip_voxelize": (C.c_int, [_ctx]),

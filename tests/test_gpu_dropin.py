@@ -22,15 +22,19 @@ DEMO = os.path.join(ROOT, "integration", "_ref", "sph_dropin_demo")
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
 
 
-@pytest.mark.parametrize("steps", [1, 3])
-def test_dropin_program_reproduces_reference_goldens(hiplib, tmp_path, steps):
+def run_demo(tmp_path, steps, full=False, sync=False):
     if not os.path.exists(DEMO):
         pytest.skip("integration/_ref/sph_dropin_demo not built (needs the reference tree)")
     out = str(tmp_path / "state.bin")
     env = dict(os.environ)
     env.pop("SPH_HIP_FULL", None)
+    env.pop("SPH_DROPIN_SYNC_MIRROR", None)
+    if full:
+        env["SPH_HIP_FULL"] = "1"
+    if sync:
+        env["SPH_DROPIN_SYNC_MIRROR"] = "1"
     try:
-        res = subprocess.run([DEMO, str(steps), out], capture_output=True, text=True, timeout=120,
+        res = subprocess.run([DEMO, str(steps), out], capture_output=True, text=True, timeout=300,
                              env=env)
     except OSError as exc:
         pytest.skip("cannot execute the demo binary here: %s" % exc)
@@ -41,13 +45,52 @@ def test_dropin_program_reproduces_reference_goldens(hiplib, tmp_path, steps):
     n = int(np.frombuffer(raw[:4], np.int32)[0])
     assert n == 32 * 1024
     f = np.frombuffer(raw[4:4 + 4 * 10 * n], np.float32)
-    pos, vel, rho, acc = f[:3 * n], f[3 * n:6 * n], f[6 * n:7 * n], f[7 * n:10 * n]
-    cnt = np.frombuffer(raw[4 + 40 * n:4 + 44 * n], np.int32)
-    in_grid = int(np.frombuffer(raw[4 + 44 * n:], np.int64)[0])
+    state = dict(pos=f[:3 * n], vel=f[3 * n:6 * n], rho=f[6 * n:7 * n], acc=f[7 * n:10 * n],
+                 ncount=np.frombuffer(raw[4 + 40 * n:4 + 44 * n], np.int32),
+                 in_grid=int(np.frombuffer(raw[4 + 44 * n:], np.int64)[0]))
+    early = [int(l.split()[1]) for l in res.stdout.splitlines() if "returned before their snapshot" in l]
+    return state, (early[0] if early else None)
+
+
+@pytest.mark.parametrize("steps", [1, 3, 500])
+def test_dropin_program_reproduces_reference_goldens(hiplib, tmp_path, steps):
+    """The host mirrors are double-buffered and filled asynchronously (the GUI never waits, the
+    solver never stalls on PCIe): step() must come back while its snapshot is still travelling,
+    and once the program waits for the last one (sph_dropin_sync_mirror) the mirrors hash to the
+    reference's own goldens - 500 steps included."""
+    state, early = run_demo(tmp_path, steps)
     g = GOLDEN["ref_sphere_M32_steps%d" % steps]["sha256"]
-    assert sha(cnt) == g["ncount"]
-    assert sha(rho) == g["rho"]
-    assert sha(acc) == g["acc"]
-    assert sha(pos) == g["pos"]
-    assert sha(vel) == g["vel"]
-    assert in_grid == n          # getGrid()[i].count() mirrors sum to the particle count
+    for k in ("ncount", "rho", "acc", "pos", "vel"):
+        assert sha(state[k]) == g[k], k
+    assert state["in_grid"] == 32 * 1024     # getGrid()[i].count() mirrors sum to the particle count
+    assert early is not None and early >= (steps + 1) // 2, \
+        "step() waited for the mirror copy in %d of %d calls" % (steps - (early or 0), steps)
+
+
+def test_dropin_blocking_mirror_is_the_same(hiplib, tmp_path):
+    """SPH_DROPIN_SYNC_MIRROR=1: every step() waits for its own snapshot (the reference's
+    behaviour: the mirror IS the state); same bits."""
+    state, early = run_demo(tmp_path, 3, sync=True)
+    g = GOLDEN["ref_sphere_M32_steps3"]["sha256"]
+    for k in ("ncount", "rho", "acc", "pos", "vel"):
+        assert sha(state[k]) == g[k], k
+    assert early == 0
+
+
+def test_dropin_full_mode_mirrors_the_voxel_grid_too(hiplib, tmp_path):
+    """SPH_HIP_FULL=1: complete neighbourhoods; getGrid()[i].count() is still served (on the
+    reference's voxel grid, which is not the grid FULL mode sorts by), and the per-particle
+    mirrors equal the library's FULL-mode run of the same scene."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    state, _ = run_demo(tmp_path, 3, full=True)
+    assert state["in_grid"] == 32 * 1024
+    p, pos, vel, mass = scenes.reference_sphere(32 * 1024)
+    with S.SPH(mass.size, p, mode=S.MODE_FULL) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.run(3)
+        part = sph.getParticles()
+        assert np.array_equal(state["pos"], part.mPosition)
+        assert np.array_equal(state["rho"], part.mDensity)
+        assert np.array_equal(state["acc"], part.mAcceleration)
+        assert np.array_equal(state["ncount"], part.mNeighborCount)

@@ -89,8 +89,18 @@ def test_first_particle_of_default_scene_matches_survey(oracle):
 def test_ref_mode_steps_match_reference_golden(oracle, case):
     g = GOLDEN[case]
     p, pos, vel, mass = inputs(oracle, case)
-    for _ in range(g["steps"]):
+    marks = {int(k): v for k, v in g.get("checkpoints", {}).items()}
+    for step in range(1, g["steps"] + 1):
         out = oracle.step(p, pos, vel, mass, mode="ref")
+        if step in marks:   # long runs: the state on the way, so that a break can be dated
+            got = dict(pos=pos, vel=vel, rho=out["rho"], acc=out["acc"], ncount=out["ncount"])
+            for name, want in marks[step]["sha256"].items():
+                assert sha(got[name]) == want, "%s %s at step %d" % (case, name, step)
+            assert out["ke"] == marks[step]["ke"] and out["pe"] == marks[step]["pe"]
+    if "particles_outside_box" in g:   # the clamp path of voxelizeParticles is really exercised
+        x = pos.reshape(-1, 3)
+        outside = ((x < 0) | (x >= np.float32([p.max_x, p.max_y, p.max_z]))).any(axis=1)
+        assert int(outside.sum()) == g["particles_outside_box"] > 50
     check(case, dict(pos=pos, vel=vel, rho=out["rho"], acc=out["acc"], ncount=out["ncount"]))
     assert int(out["ncount"].sum()) == g["neighbors_total"]
     assert out["ke"] == g["ke"] and out["pe"] == g["pe"]     # same serial fp32 sums
