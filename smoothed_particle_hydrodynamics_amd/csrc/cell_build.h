@@ -16,6 +16,15 @@
 #ifndef RANK_UNROLL
 #define RANK_UNROLL 4   // cell members compared per trip of the in-cell ranking (FULL mode)
 #endif
+// Cells with more members than this are ranked by k_rank_big (sorted in LDS) instead of by every
+// member scanning the whole cell: the scan is O(m^2) per cell, fine at the 8 particles per cell
+// of a fluid at rest, ruinous for a cell that holds a large part of the scene - out-of-box
+// particles are clamped into the edge cells exactly as the reference does (src/sph.cpp:456-463).
+#ifndef RANK_BIG
+#define RANK_BIG 512
+#endif
+#define RANK_CHUNK 4096   // members sorted at a time in LDS (key + source index: 32 KiB)
+#define RANK_BIG_BLOCKS 256
 #define SCAN_ITEMS 16
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
@@ -168,8 +177,9 @@ k_scan_parts(uint32_t* __restrict__ part, int ntiles)
 // writes cell_start[0..ncells] and clears the counts for the next build
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restrict__ part,
-             uint32_t* __restrict__ cell_start)
+             uint32_t* __restrict__ cell_start, uint32_t* __restrict__ big_cells)
 {
+   if (blockIdx.x == 0 && threadIdx.x == 0) big_cells[0] = 0u;   // k_scatter lists this build's big cells
    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
    uint32_t v[SCAN_ITEMS];
    uint32_t s = 0;
@@ -223,13 +233,21 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
           const uint32_t* __restrict__ cell_start, int32_t* __restrict__ meta,
           uint32_t* __restrict__ perm, int cells_per_plane, int ncells, int own_lo, int own_hi,
           int sum_lo, int sum_hi, int bnd_lo, int bnd_hi, int32_t* __restrict__ tile_stats,
-          int32_t* __restrict__ clear_a, int32_t* __restrict__ clear_b)
+          int32_t* __restrict__ clear_a, int32_t* __restrict__ clear_b,
+          uint32_t* __restrict__ big_cells)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    // tile statistics of the step: the descriptor pass accumulates into them
    if (tile_stats && i < TSTAT_COUNT && i != TSTAT_BLOCKS) tile_stats[i] = 0;
    const int n_in = meta[META_N_IN];
-   if (i < n_in) perm[cell_start[key[i]] + slot[i]] = (uint32_t)i;
+   if (i < n_in) {
+      const uint32_t c = key[i], first = cell_start[c], sl = slot[i];
+      perm[first + sl] = (uint32_t)i;
+      // the cell's first arrival lists it when it is too crowded for the per-member ranking scan
+      // (the trash cell's entries are dropped, not ranked)
+      if (sl == 0u && c != (uint32_t)ncells && cell_start[c + 1] - first > (uint32_t)RANK_BIG)
+         big_cells[1u + atomicAdd(&big_cells[0], 1u)] = c;
+   }
    if (i == 0) {
       // Sorted ranges of the slab (kept out of a launch of their own: a kernel boundary costs
       // more than this does): live entries, owned planes [lo, hi), density planes one wider.
@@ -262,6 +280,7 @@ k_rank_order(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key
    const uint32_t i = perm[p];
    const uint32_t c = key[i];
    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+   if (e - s > (uint32_t)RANK_BIG) return;   // a crowded cell: k_rank_big sorts it
    uint32_t rank = 0;
    // eight cell members per trip (independent loads; positions past the end re-read the last)
    for (uint32_t q0 = s; q0 < e; q0 += 8) {
@@ -279,13 +298,15 @@ __device__ __forceinline__ void
 rank_gather(int p, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
             const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, int trash,
             const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
-            float4* __restrict__ posm_out, float4* __restrict__ velp_out)
+            float4* __restrict__ posm_out, float4* __restrict__ velp_out,
+            uint32_t* __restrict__ remap = nullptr)
 {
    if (p >= meta[META_N_IN]) return;
    const uint32_t i = perm[p];
    const uint32_t c = key[i];
    if (c == (uint32_t)trash) return;  // dead entries are dropped: the live set is compacted
    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+   if (e - s > (uint32_t)RANK_BIG) return;   // a crowded cell: k_rank_big sorts it
    const float4 v = velp_in[i];
    const uint32_t id = __float_as_uint(v.w);
    uint32_t rank = 0;
@@ -301,14 +322,138 @@ rank_gather(int p, const uint32_t* __restrict__ perm, const uint32_t* __restrict
    }
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;
+   if (remap) remap[i] = s + rank;   // stand-alone sph_hip_voxelize: where entry i went
 }
 
 __global__ void __launch_bounds__(256)
 k_rank_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key,
               const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, int trash,
               const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
-              float4* __restrict__ posm_out, float4* __restrict__ velp_out)
+              float4* __restrict__ posm_out, float4* __restrict__ velp_out,
+              uint32_t* __restrict__ remap)
 {
    rank_gather(blockIdx.x * blockDim.x + threadIdx.x, perm, key, cell_start, meta, trash, posm_in,
-               velp_in, posm_out, velp_out);
+               velp_in, posm_out, velp_out, remap);
+}
+
+// ---- 4c. crowded cells: sort by key in LDS, O(m log^2 m) instead of O(m^2) ----------------------
+// One workgroup per listed cell (grid-stride over the list k_scatter made).  The cell's members are
+// sorted RANK_CHUNK at a time by a bitonic network in LDS on (key, source index) - key = the
+// persistent id (FULL) or the particle index itself (REF), both unique.  A cell of one chunk is
+// placed straight from LDS.  A larger one writes its sorted chunks to a global scratch; every
+// member's rank is then its index in its own chunk plus, for every other chunk, the number of
+// smaller keys there (binary search): O(m * m / RANK_CHUNK * log RANK_CHUNK) loads, by the one
+// workgroup that wrote the chunks (its own global writes are visible to it after a barrier).
+template <bool FULL>
+__global__ void __launch_bounds__(256)
+k_rank_big(const uint32_t* __restrict__ big_cells, const uint32_t* __restrict__ perm,
+           const uint32_t* __restrict__ cell_start, const float4* __restrict__ posm_in,
+           const float4* __restrict__ velp_in, float4* __restrict__ posm_out,
+           float4* __restrict__ velp_out, uint32_t* __restrict__ order,
+           uint32_t* __restrict__ scratch_key, uint32_t* __restrict__ scratch_src,
+           uint32_t* __restrict__ remap)
+{
+   __shared__ uint32_t skey[RANK_CHUNK], ssrc[RANK_CHUNK];
+   const int tid = threadIdx.x;
+   const uint32_t nbig = big_cells[0];
+   for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+      const uint32_t c = big_cells[1u + b];
+      const uint32_t s = cell_start[c], m = cell_start[c + 1] - s;
+      const uint32_t nchunks = (m + RANK_CHUNK - 1) / RANK_CHUNK;
+      for (uint32_t ch = 0; ch < nchunks; ch++) {
+         const uint32_t base = ch * RANK_CHUNK;
+         const uint32_t len = min((uint32_t)RANK_CHUNK, m - base);
+         uint32_t padded = 256;                        // power of two >= len
+         while (padded < len) padded <<= 1;
+         for (uint32_t t = tid; t < padded; t += 256) {
+            uint32_t key = 0xffffffffu, src = 0u;      // padding sorts to the end
+            if (t < len) {
+               src = perm[s + base + t];
+               key = FULL ? __float_as_uint(velp_in[src].w) : src;
+            }
+            skey[t] = key;
+            ssrc[t] = src;
+         }
+         __syncthreads();
+         for (uint32_t k2 = 2; k2 <= padded; k2 <<= 1) {
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+               for (uint32_t t = tid; t < padded; t += 256) {
+                  const uint32_t partner = t ^ j;
+                  if (partner > t) {
+                     const bool up = (t & k2) == 0;
+                     const uint32_t a = skey[t], bb = skey[partner];
+                     if ((a > bb) == up) {
+                        skey[t] = bb;
+                        skey[partner] = a;
+                        const uint32_t sa = ssrc[t];
+                        ssrc[t] = ssrc[partner];
+                        ssrc[partner] = sa;
+                     }
+                  }
+               }
+               __syncthreads();
+            }
+         }
+         for (uint32_t t = tid; t < len; t += 256) {
+            if (nchunks == 1) {                        // ascending key = final order of the cell
+               const uint32_t src = ssrc[t];
+               if (FULL) {
+                  posm_out[s + t] = posm_in[src];
+                  velp_out[s + t] = velp_in[src];
+                  if (remap) remap[src] = s + t;
+               } else {
+                  order[s + t] = src;
+               }
+            } else {
+               scratch_key[s + base + t] = skey[t];
+               scratch_src[s + base + t] = ssrc[t];
+            }
+         }
+         __syncthreads();
+      }
+      if (nchunks > 1) {
+         for (uint32_t idx = tid; idx < m; idx += 256) {
+            const uint32_t key = scratch_key[s + idx], mine = idx / RANK_CHUNK;
+            uint32_t rank = idx % RANK_CHUNK;
+            for (uint32_t ch = 0; ch < nchunks; ch++) {
+               if (ch == mine) continue;
+               const uint32_t* keys = scratch_key + s + ch * RANK_CHUNK;
+               uint32_t lo = 0, hi = min((uint32_t)RANK_CHUNK, m - ch * RANK_CHUNK);
+               while (lo < hi) {                       // first position with keys[pos] >= key
+                  const uint32_t mid = (lo + hi) >> 1;
+                  if (keys[mid] < key) lo = mid + 1;
+                  else hi = mid;
+               }
+               rank += lo;
+            }
+            const uint32_t src = scratch_src[s + idx];
+            if (FULL) {
+               posm_out[s + rank] = posm_in[src];
+               velp_out[s + rank] = velp_in[src];
+               if (remap) remap[src] = s + rank;
+            } else {
+               order[s + rank] = src;
+            }
+         }
+         __syncthreads();
+      }
+   }
+}
+
+// Stand-alone sph_hip_voxelize (FULL mode re-sorts the state): the per-particle results of the
+// last sums follow their particles into the new order (remap[i] = new position of entry i), as
+// SPH::voxelizeParticles() leaves Particle::mDensity / mAcceleration / mNeighborCount valid.
+__global__ void __launch_bounds__(256)
+k_permute_sums(const uint32_t* __restrict__ remap, const uint32_t* __restrict__ key,
+               const int32_t* __restrict__ meta, uint32_t trash, const float* __restrict__ rho,
+               const float4* __restrict__ acc, const int32_t* __restrict__ ncount,
+               float* __restrict__ rho_out, float4* __restrict__ acc_out,
+               int32_t* __restrict__ ncount_out)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= meta[META_N_IN] || key[i] == trash) return;
+   const uint32_t j = remap[i];
+   rho_out[j] = rho[i];
+   acc_out[j] = acc[i];
+   ncount_out[j] = ncount[i];
 }

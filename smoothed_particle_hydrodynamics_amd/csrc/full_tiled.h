@@ -221,7 +221,8 @@ k_rank_gather_tile_desc(int desc_blocks, int ntiles, const uint32_t* __restrict_
                         const float4* __restrict__ posm_in, const float4* __restrict__ velp_in,
                         float4* __restrict__ posm_out, float4* __restrict__ velp_out,
                         TileDesc* __restrict__ desc, TileCaps caps, int32_t* __restrict__ stats,
-                        uint32_t* __restrict__ giveup_density, uint32_t* __restrict__ giveup_accel)
+                        uint32_t* __restrict__ giveup_density, uint32_t* __restrict__ giveup_accel,
+                        uint32_t* __restrict__ remap)
 {
    if ((int)blockIdx.x < desc_blocks) {
       tile_desc(blockIdx.x * blockDim.x + threadIdx.x, ntiles, perm, key, cell_start, meta, g, desc,
@@ -229,7 +230,7 @@ k_rank_gather_tile_desc(int desc_blocks, int ntiles, const uint32_t* __restrict_
       return;
    }
    rank_gather((blockIdx.x - desc_blocks) * blockDim.x + threadIdx.x, perm, key, cell_start, meta,
-               g.ncells, posm_in, velp_in, posm_out, velp_out);
+               g.ncells, posm_in, velp_in, posm_out, velp_out, remap);
 }
 
 __device__ __forceinline__ void tile_desc_load(const TileDesc* __restrict__ desc, int wg, TileDesc& sd)

@@ -137,6 +137,7 @@ struct sph_hip_context {
    uint32_t* cell_count = nullptr; // ncells
    uint32_t* cell_start = nullptr; // ncells + 1
    uint32_t* scan_part = nullptr;  // per-tile partial sums of the scan
+   uint32_t* big_cells = nullptr;  // [0] = count, then the cells with more than RANK_BIG members
    int scan_tiles = 0;
 
    // sums

@@ -87,7 +87,7 @@ void free_all(sph_hip_context* ctx)
       if (ctx->velp[b]) (void)hipFree(ctx->velp[b]);
    }
    void* ptrs[] = {ctx->key, ctx->slot, ctx->perm, ctx->order, ctx->cell_count, ctx->cell_start,
-                   ctx->scan_part, ctx->rho, ctx->velB, ctx->auxc, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
+                   ctx->scan_part, ctx->big_cells, ctx->rho, ctx->velB, ctx->auxc, ctx->acc, ctx->ncount, ctx->vox, ctx->nb,
                    ctx->nd, ctx->epart, ctx->stats, ctx->stage, ctx->tile_desc, ctx->meta, ctx->nlist,
                    ctx->nlist_overflow, ctx->tile_stats, ctx->giveup_density, ctx->giveup_accel};
    for (void* q : ptrs)
@@ -299,7 +299,8 @@ SlabZone slab_zone(const sph_hip_context* ctx)
 }
 
 // clear_left/right: message buffers whose record counters this build zeroes (early exchange)
-int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* clear_right = nullptr)
+int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* clear_right = nullptr,
+                      bool keep_sums = false)
 {
    const int n = ctx->n;  // host upper bound of entries; the exact count is meta[META_N_IN]
    if (n == 0) return SPH_HIP_OK;
@@ -331,7 +332,7 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
                       ncells_scan, ctx->scan_part);
    hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(SCAN_THREADS), 0, st, ctx->scan_part, tiles);
    hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
-                      ncells_scan, ctx->scan_part, ctx->cell_start);
+                      ncells_scan, ctx->scan_part, ctx->cell_start, ctx->big_cells);
    // sorted ranges: owned planes [lo, hi), density planes one wider (clipped to what is held)
    const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
    const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
@@ -344,10 +345,22 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
                       ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
                       sum_lo, sum_hi, bnd_lo, bnd_hi, ctx->tile_stats, (int32_t*)clear_left,
-                      (int32_t*)clear_right);
+                      (int32_t*)clear_right, ctx->big_cells);
+   // crowded cells (listed by k_scatter; none in an ordinary scene: the workgroups then leave at
+   // once) are ranked by sorting, behind the per-member scan that skips them; scratch = the
+   // staging buffer, idle during a step
+   uint32_t* scratch_key = reinterpret_cast<uint32_t*>(ctx->stage);
+   uint32_t* scratch_src = scratch_key + ctx->capacity;
+   // keep_sums (stand-alone voxelize of a FULL-mode context that holds the whole grid): note where
+   // every entry goes (in `slot`, free once k_scatter has run) and move rho / acc / ncount along
+   uint32_t* remap = (keep_sums && ctx->mode == SPH_HIP_MODE_FULL && !ctx->had_exchange) ? ctx->slot : nullptr;
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_rank_order, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
                          ctx->cell_start, ctx->meta, ctx->order);
+      hipLaunchKernelGGL(k_rank_big<false>, dim3(RANK_BIG_BLOCKS), dim3(256), 0, st, ctx->big_cells,
+                         ctx->perm, ctx->cell_start, (const float4*)nullptr, (const float4*)nullptr,
+                         (float4*)nullptr, (float4*)nullptr, ctx->order, scratch_key, scratch_src,
+                         (uint32_t*)nullptr);
    } else {
       const int nxt = cur ^ 1;
       if (ctx->use_tiled) {
@@ -360,11 +373,26 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
                             desc_blocks, ntiles, ctx->perm, ctx->key, ctx->cell_start, ctx->meta,
                             g, ctx->posm[cur], ctx->velp[cur], ctx->posm[nxt], ctx->velp[nxt],
                             ctx->tile_desc, ctx->caps, ctx->tile_stats, ctx->giveup_density,
-                            ctx->giveup_accel);
+                            ctx->giveup_accel, remap);
       } else {
          hipLaunchKernelGGL(k_rank_gather, dim3(blocks), dim3(256), 0, st, ctx->perm, ctx->key,
                             ctx->cell_start, ctx->meta, g.ncells, ctx->posm[cur], ctx->velp[cur],
-                            ctx->posm[nxt], ctx->velp[nxt]);
+                            ctx->posm[nxt], ctx->velp[nxt], remap);
+      }
+      hipLaunchKernelGGL(k_rank_big<true>, dim3(RANK_BIG_BLOCKS), dim3(256), 0, st, ctx->big_cells,
+                         ctx->perm, ctx->cell_start, ctx->posm[cur], ctx->velp[cur], ctx->posm[nxt],
+                         ctx->velp[nxt], (uint32_t*)nullptr, scratch_key, scratch_src, remap);
+      if (remap) {
+         // a build that is not followed by the sums: their last results move with the particles
+         // (temporaries in the staging buffer behind k_rank_big's scratch; the float4 part 16-byte aligned)
+         float4* acc_t = reinterpret_cast<float4*>(ctx->stage + ((2 * (size_t)ctx->capacity + 3) & ~(size_t)3));
+         float* rho_t = reinterpret_cast<float*>(acc_t + (size_t)ctx->capacity);
+         int32_t* cnt_t = reinterpret_cast<int32_t*>(rho_t + (size_t)ctx->capacity);
+         hipLaunchKernelGGL(k_permute_sums, dim3(blocks), dim3(256), 0, st, remap, ctx->key, ctx->meta,
+                            (uint32_t)g.ncells, ctx->rho, ctx->acc, ctx->ncount, rho_t, acc_t, cnt_t);
+         SPH_TRY(hipMemcpyAsync(ctx->rho, rho_t, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+         SPH_TRY(hipMemcpyAsync(ctx->acc, acc_t, sizeof(float4) * n, hipMemcpyDeviceToDevice, st));
+         SPH_TRY(hipMemcpyAsync(ctx->ncount, cnt_t, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
       }
       ctx->cur = nxt;
       // The live set is now compacted at the front of the new buffers.  meta[N_IN] still holds
@@ -803,6 +831,8 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    CREATE_TRY(dev_alloc(&ctx->cell_count, cells_padded));
    CREATE_TRY(dev_alloc(&ctx->cell_start, cells_padded));
    CREATE_TRY(dev_alloc(&ctx->scan_part, (size_t)ctx->scan_tiles + 1));
+   CREATE_TRY(dev_alloc(&ctx->big_cells, cap / RANK_BIG + 2));
+   CREATE_TRY(hipMemsetAsync(ctx->big_cells, 0, sizeof(uint32_t), ctx->stream));
    CREATE_TRY(hipMemsetAsync(ctx->cell_count, 0, cells_padded * sizeof(uint32_t), ctx->stream));
    CREATE_TRY(hipMemsetAsync(ctx->cell_start, 0, cells_padded * sizeof(uint32_t), ctx->stream));
    CREATE_TRY(dev_alloc(&ctx->rho, cap));
@@ -1518,7 +1548,9 @@ int sph_hip_run(sph_hip_context* ctx, int steps)
 int sph_hip_voxelize(sph_hip_context* ctx)
 {
    int rc = check_ctx(ctx);
-   return rc ? rc : launch_cell_build(ctx);
+   // FULL mode keeps the state cell-sorted, so this call moves the particles in device memory:
+   // density, acceleration and neighbour counts of the last sums move with them
+   return rc ? rc : launch_cell_build(ctx, nullptr, nullptr, true);
 }
 
 int sph_hip_find_neighbors(sph_hip_context* ctx)

@@ -372,3 +372,69 @@ def test_full_context_reuse_with_a_different_scene(oracle, hiplib):
             check_state(part, ref, "scene %d" % k)
             assert np.array_equal(part.mPosition, opos)
             assert np.array_equal(part.mVelocity, ovel)
+
+
+def crowded_scene(n_far, n_mid, n_box, seed=21):
+    """n_far particles beyond the box corner (all clamped into the last cell, as the reference
+    clamps them, src/sph.cpp:456-463), n_mid packed into one interior cell, n_box ordinary ones."""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, far, _, _ = scenes.dense_block(n_far, lo=(6.45, 6.5, 6.6), hi=(6.95, 7.0, 7.1), seed=seed)
+    _, mid, _, _ = scenes.dense_block(n_mid, lo=(2.005, 3.005, 1.005), hi=(2.095, 3.095, 1.095), seed=seed + 1)
+    _, box, vel, _ = scenes.dense_block(n_box, lo=(1.0, 1.0, 1.0), hi=(3.0, 3.5, 2.0), seed=seed + 2, speed=5.0)
+    pos = np.concatenate([far, mid, box])
+    n = n_far + n_mid + n_box
+    vel = scenes.box_fill(n, (-3.0,) * 3, (3.0,) * 3, seed + 3)
+    # shuffle, so that persistent ids are not already in any helpful order
+    order = np.random.default_rng(seed).permutation(n)
+    pos = np.ascontiguousarray(pos.reshape(-1, 3)[order]).reshape(-1)
+    return p, pos, np.ascontiguousarray(vel), np.ones(n, np.float32)
+
+
+def test_full_crowded_cells_are_ranked_by_sorting(oracle, hiplib):
+    """A cell holding 20 000 particles (five LDS chunks) and one holding 3 000 (one chunk): the
+    in-cell order comes from k_rank_big's sort instead of the O(m^2) scan - same canonical order,
+    same bits as the oracle, in bounded time."""
+    import time
+    import smoothed_particle_hydrodynamics_amd as S
+    p, pos, vel, mass = crowded_scene(20000, 3000, 4000)
+    opos, ovel = pos.copy(), vel.copy()
+    with S.SPH(mass.size, p, mode=S.MODE_FULL) as sph:
+        sph.setParticles(pos, vel, mass)
+        t0 = time.perf_counter()
+        sph.step()
+        sph.synchronize()
+        assert time.perf_counter() - t0 < 20.0
+        ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+        part = sph.getParticles()
+        check_state(part, ref, "crowded")
+        assert np.array_equal(part.mPosition, opos)
+        assert part.mNeighborCount.max() > 400
+
+
+def test_full_standalone_voxelize_keeps_the_sums_with_their_particles(oracle, hiplib):
+    """SPH::voxelizeParticles() leaves Particle::mDensity / mAcceleration / mNeighborCount valid
+    (reference src/sph.cpp:438-481 touches none of them).  In FULL mode the call re-sorts the
+    state in device memory; the per-particle results of the last sums must move along, or a
+    download pairs them with the wrong particles."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(30000, lo=(1.0, 1.0, 1.0), hi=(2.0, 2.0, 2.0), speed=60.0)
+    with S.SPH(mass.size, p, mode=S.MODE_FULL) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.step()                       # the integrate moved particles across cells
+        before = sph.getParticles()
+        want = {k: getattr(before, k).copy() for k in
+                ("mPosition", "mVelocity", "mDensity", "mAcceleration", "mNeighborCount")}
+        sph.voxelizeParticles()          # re-sorts: new order in device memory
+        after = sph.getParticles()
+        for k, v in want.items():
+            assert np.array_equal(getattr(after, k), v), k
+        # and the pipeline continues from there exactly like an uninterrupted one
+        sph.voxelizeParticles()
+        sph.computeDensity()
+        sph.computeAcceleration()
+        sph.integrate()
+        opos, ovel = pos.copy(), vel.copy()
+        for _ in range(2):
+            ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+        check_state(sph.getParticles(), ref, "after stand-alone voxelize")
