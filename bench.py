@@ -234,6 +234,11 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     cap, msg = SL.slab_capacities(hist, cuts, rank, slack=1.5)
     mine = np.nonzero((planes >= cuts[rank]) & (planes < cuts[rank + 1]))[0]
     del z, planes
+    def make_slab(new_cuts, r, plane_hist):
+        c, m = SL.slab_capacities(np.asarray(plane_hist), new_cuts, r, slack=1.5)
+        return SL.HipSlab(p, new_cuts[r], new_cuts[r + 1], c, max(m, msg), device=local_rank,
+                          has_left=r > 0, has_right=r + 1 < world)
+
     slab = SL.HipSlab(p, cuts[rank], cuts[rank + 1], cap, msg, device=local_rank,
                       has_left=rank > 0, has_right=rank + 1 < world)
     slab.upload(mine.astype(np.uint32), scenes.box_fill_subset(mine, (0.0, 0.0, 0.0), hi),
@@ -246,7 +251,10 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
         stepper = SL.NativeSlabStepper(slab, rank, world)
     else:
         transport = (SL.HostStagedTransport if mode == "host" else SL.DistTransport)(rank, world)
-        stepper = SL.DistSlabStepper(slab, transport)
+        # cuts are re-evaluated every 500 steps (a count per rank; particles move only when the
+        # fullest slab is 10 % over the mean), the message size every 256
+        stepper = SL.DistSlabStepper(slab, transport, make_slab=make_slab, cuts=cuts,
+                                     rebalance_every=500, imbalance=1.1, trim_every=256)
 
     def fence():
         slab.synchronize()
@@ -256,6 +264,9 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     slab.set_timing(S.TIMING_SUMS)
     for _ in range(warmup):
         stepper.step()
+    fence()
+    # from here on only the used part of the halo messages crosses the links (+25 % head room)
+    msg_records = stepper.trim_messages() if warmup > 0 else slab.msg_capacity
     fence()
     slab.reset_timings()
     t0 = time.perf_counter()
@@ -284,6 +295,8 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     return {"params": p, "dt": dt, "totals": totals, "covered": covered, "n": n,
             "n_rank": st["owned"], "neighbors_mean": nb_mean, "steps": steps, "box": box,
             "ranks": dist.get_world_size(),
+            "halo_message_bytes": SL.message_bytes(msg_records),
+            "halo_message_bytes_allocated": SL.message_bytes(slab.msg_capacity),
             "parallelism": "z-slab x%d, RCCL halo (%s)" % (
                 world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so",
                         "host": "host-staged rehearsal"}.get(mode, "torch.distributed P2P"))}
@@ -380,6 +393,8 @@ def main():
         r = run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, args.steps, args.warmup)
         p, dt, totals, covered = r["params"], r["dt"], r["totals"], r["covered"]
         n_rank, nb_mean, par, ranks = r["n_rank"], r["neighbors_mean"], r["parallelism"], r["ranks"]
+        halo = {"bytes_per_message": r["halo_message_bytes"],
+                "bytes_allocated": r["halo_message_bytes_allocated"]}
         if args.scaling == "strong" and not args.no_one_gpu_reference:
             # the same scene on one GPU, same run: what the N-GPU time is a speedup OF
             one_ms = None
@@ -486,6 +501,8 @@ def main():
                         "64 B/particle compulsory-traffic figure of SURVEY.md 8(d)",
             },
         }
+        if world > 1:
+            line["config"]["halo"] = halo
         if strong_scaling is not None:
             line["strong_scaling"] = strong_scaling
         if other is not None:

@@ -272,6 +272,9 @@ int sph_hip_slab_upload(sph_hip_context* ctx, int n, const float* pos, const flo
 int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uint32_t* ids,
                           float* pos, float* vel, float* density, float* acc,
                           int32_t* neighbor_count);
+/* Masses of the owned particles in the row order of sph_hip_slab_download (what a host needs,
+ * with that call's arrays, to move particles to another slab: slab.py rebalance()). */
+int sph_hip_slab_download_mass(sph_hip_context* ctx, int max_rows, int32_t* rows, float* mass);
 size_t sph_hip_slab_message_bytes(int capacity_records);
 /* NULL for a side without neighbour.  Call after sph_hip_step()/upload, before the transport. */
 int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_device,
@@ -300,6 +303,15 @@ int sph_hip_rccl_unique_id(void* id_out, int id_bytes);
 int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, int rank, int nranks,
                            int capacity_records);
 int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps);
+/* Only the used part of a message needs to cross the link.  Collective over the communicator
+ * (synchronises): every rank looks at the record counts of the messages it packed last, the
+ * largest count * slack + extra_records (at most the capacity given to sph_hip_slab_comm_init)
+ * becomes the size every message is packed for, sent and received with from now on
+ * (*active_records).  A message that outgrows it raises error bit 2, which stops
+ * sph_hip_slab_comm_run: trim again with more head room.  Call after a few steps, and now and
+ * then in a long run. */
+int sph_hip_slab_comm_trim(sph_hip_context* ctx, float slack, int extra_records,
+                           int32_t* active_records);
 int sph_hip_slab_comm_selftest(sph_hip_context* ctx);
 /* Diagnostics (synchronises): live entries, owned particles, error bits (1: a received entry
  * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded,

@@ -236,6 +236,15 @@ k_export(const float4* __restrict__ posm, const float4* __restrict__ velp,
    if (ocount) ocount[id] = ncount[p];
 }
 
+// masses of the owned particles, row p - own_begin (the row order of a compact k_export)
+__global__ void __launch_bounds__(256)
+k_export_mass(const float4* __restrict__ posm, const int32_t* __restrict__ meta, float* __restrict__ mass)
+{
+   const int p = meta[META_OWN_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_OWN_END]) return;
+   mass[p - meta[META_OWN_BEGIN]] = posm[p].w;
+}
+
 // per-voxel occupancy on the REFERENCE voxel grid (edge mCellSize = 2h, reference
 // src/sph.cpp:438-481) whatever grid the context sorts by: what getGrid()[i].count() readers get
 __global__ void __launch_bounds__(256)

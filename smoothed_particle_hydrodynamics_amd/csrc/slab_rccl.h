@@ -21,6 +21,8 @@ struct RcclApi {
    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                             hipStream_t) = nullptr;
    ncclResult_t (*GroupStart)() = nullptr;
    ncclResult_t (*GroupEnd)() = nullptr;
    const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -60,6 +62,7 @@ inline const RcclApi* rccl_api(std::string* why)
          SPH_RCCL_SYM(CommDestroy, "ncclCommDestroy")
          SPH_RCCL_SYM(Send, "ncclSend")
          SPH_RCCL_SYM(Recv, "ncclRecv")
+         SPH_RCCL_SYM(AllReduce, "ncclAllReduce")
          SPH_RCCL_SYM(GroupStart, "ncclGroupStart")
          SPH_RCCL_SYM(GroupEnd, "ncclGroupEnd")
          SPH_RCCL_SYM(GetErrorString, "ncclGetErrorString")
@@ -84,7 +87,9 @@ struct SlabComm {
    void* send_right = nullptr;
    void* recv_left = nullptr;
    void* recv_right = nullptr;
-   int capacity_records = 0;
-   size_t bytes = 0;
+   int capacity_records = 0;          // what the buffers hold
+   int active_records = 0;            // what messages are packed for and transferred with (<= capacity)
+   size_t bytes = 0;                  // bytes of a message of active_records
+   int32_t* trim_word = nullptr;      // device int: this rank's wish, then the maximum over the ranks
    bool primed = false;               // the first ghosts have been delivered
 };

@@ -104,7 +104,7 @@ void free_all(sph_hip_context* ctx)
          const RcclApi* api = rccl_api(nullptr);
          if (api) (void)api->CommDestroy(c->comm);
       }
-      for (void* q : {c->send_left, c->send_right, c->recv_left, c->recv_right})
+      for (void* q : {c->send_left, c->send_right, c->recv_left, c->recv_right, (void*)c->trim_word})
          if (q) (void)hipFree(q);
       if (c->packed) (void)hipEventDestroy(c->packed);
       if (c->arrived) (void)hipEventDestroy(c->arrived);
@@ -1206,6 +1206,26 @@ int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uin
    return download_impl(ctx, 1, ctx->n_owned, ids, pos, vel, density, acc, neighbor_count);
 }
 
+int sph_hip_slab_download_mass(sph_hip_context* ctx, int max_rows, int32_t* rows, float* mass)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if ((rc = owned_count(ctx, nullptr))) return rc;
+   if (rows) *rows = ctx->n_owned;
+   if (!mass || ctx->n_owned > max_rows) {
+      ctx->err = "sph_hip_slab_download_mass: caller's array is missing or too small";
+      return SPH_HIP_ERR_CAPACITY;
+   }
+   if (ctx->n_owned == 0) return SPH_HIP_OK;
+   hipLaunchKernelGGL(k_export_mass, dim3(div_up(ctx->n, 256)), dim3(256), 0, ctx->stream,
+                      ctx->posm[ctx->cur], ctx->meta, ctx->stage);
+   SPH_TRY(hipGetLastError());
+   SPH_TRY(hipMemcpyAsync(mass, ctx->stage, sizeof(float) * ctx->n_owned, hipMemcpyDeviceToHost,
+                          ctx->stream));
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
 int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors)
 {
    int rc = check_ctx(ctx);
@@ -1406,7 +1426,7 @@ int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, i
    ctx->comm = c;   // from here on sph_hip_destroy cleans up
    c->rank = rank;
    c->nranks = nranks;
-   c->capacity_records = capacity_records;
+   c->capacity_records = c->active_records = capacity_records;
    c->bytes = sph_hip_slab_message_bytes(capacity_records);
    int least = 0, greatest = 0;
    SPH_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -1419,6 +1439,7 @@ int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, i
       SPH_TRY(hipMalloc(bufs[b], c->bytes));
       SPH_TRY(hipMemsetAsync(*bufs[b], 0, c->bytes, ctx->stream));
    }
+   SPH_TRY(hipMalloc((void**)&c->trim_word, sizeof(int32_t)));
    SPH_TRY(hipStreamSynchronize(ctx->stream));
    ncclUniqueId uid;
    memcpy(&uid, id, sizeof(uid));
@@ -1459,13 +1480,13 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
    hipStream_t st = ctx->stream;
    if (!c->primed) {
       // the first ghosts: pack -> send/recv -> unpack, serially
-      if ((rc = sph_hip_slab_pack(ctx, c->send_left, c->send_right, c->capacity_records))) return rc;
+      if ((rc = sph_hip_slab_pack(ctx, c->send_left, c->send_right, c->active_records))) return rc;
       SPH_TRY(hipEventRecord(c->packed, st));
       SPH_TRY(hipStreamWaitEvent(c->stream, c->packed, 0));
       if ((rc = comm_send_recv(ctx))) return rc;
       SPH_TRY(hipEventRecord(c->arrived, c->stream));
       SPH_TRY(hipStreamWaitEvent(st, c->arrived, 0));
-      if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->capacity_records))) return rc;
+      if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->active_records))) return rc;
       c->primed = true;
    }
    for (int s = 0; s < steps; s++) {
@@ -1480,17 +1501,51 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
       }
       // border planes + messages on the exchange stream, transfer behind them; the interior's
       // acceleration and the integrate meanwhile on the context's stream
-      if ((rc = sph_hip_slab_step_begin(ctx, c->send_left, c->send_right, c->capacity_records, c->stream)))
+      if ((rc = sph_hip_slab_step_begin(ctx, c->send_left, c->send_right, c->active_records, c->stream)))
          return rc;
       if ((rc = comm_send_recv(ctx))) return rc;
       SPH_TRY(hipEventRecord(c->arrived, c->stream));
       if ((rc = sph_hip_slab_step_end(ctx))) return rc;
       SPH_TRY(hipStreamWaitEvent(st, c->arrived, 0));
-      if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->capacity_records))) return rc;
+      if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->active_records))) return rc;
    }
    // the word as it stands after the last step travels behind the loop: the caller's
    // sph_hip_synchronize (or the next call of this function) reports it
    return watch_enqueue(ctx);
+}
+
+int sph_hip_slab_comm_trim(sph_hip_context* ctx, float slack, int extra_records, int32_t* active_records)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SlabComm* c = ctx->comm;
+   if (!c || !c->comm || !(slack >= 1.0f) || extra_records < 0) {
+      ctx->err = "sph_hip_slab_comm_trim: sph_hip_slab_comm_init first; slack >= 1, extra >= 0";
+      return SPH_HIP_ERR_INVALID;
+   }
+   const RcclApi* api = rccl_api(nullptr);
+   // what this rank packed last (the headers' record counts), with head room
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   SPH_TRY(hipStreamSynchronize(c->stream));
+   int32_t most = 0;
+   for (void* msg : {c->send_left, c->send_right}) {
+      if (!msg) continue;
+      int32_t n = 0;
+      SPH_TRY(hipMemcpy(&n, msg, sizeof(n), hipMemcpyDeviceToHost));
+      most = n > most ? n : most;
+   }
+   double want_d = (double)most * (double)slack + (double)extra_records;
+   int32_t want = want_d > (double)c->capacity_records ? c->capacity_records : (int32_t)want_d;
+   // every message of the run has one size: the largest wish of any rank
+   SPH_TRY(hipMemcpy(c->trim_word, &want, sizeof(want), hipMemcpyHostToDevice));
+   SPH_NCCL_TRY(api->AllReduce(c->trim_word, c->trim_word, 1, ncclInt32, ncclMax, c->comm, c->stream));
+   SPH_TRY(hipStreamSynchronize(c->stream));
+   SPH_TRY(hipMemcpy(&want, c->trim_word, sizeof(want), hipMemcpyDeviceToHost));
+   if (want < 1) want = 1;
+   c->active_records = want;
+   c->bytes = sph_hip_slab_message_bytes(want);
+   if (active_records) *active_records = want;
+   return SPH_HIP_OK;
 }
 
 int sph_hip_slab_comm_selftest(sph_hip_context* ctx)

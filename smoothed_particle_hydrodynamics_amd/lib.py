@@ -94,6 +94,7 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_int]),
     "sph_hip_slab_download": (C.c_int, [_ctx, C.c_int, _P(C.c_int32), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sph_hip_slab_download_mass": (C.c_int, [_ctx, C.c_int, _P(C.c_int32), C.c_void_p]),
     "sph_hip_slab_message_bytes": (C.c_size_t, [C.c_int]),
     "sph_hip_slab_pack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
     "sph_hip_slab_unpack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "sph_hip_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
     "sph_hip_slab_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sph_hip_slab_comm_run": (C.c_int, [_ctx, C.c_int]),
+    "sph_hip_slab_comm_trim": (C.c_int, [_ctx, C.c_float, C.c_int, _P(C.c_int32)]),
     "sph_hip_slab_comm_selftest": (C.c_int, [_ctx]),
     "sph_hip_slab_status": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "sph_hip_slab_poll_errors": (C.c_int, [_ctx, _P(C.c_int32)]),

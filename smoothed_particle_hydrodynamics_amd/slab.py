@@ -34,16 +34,15 @@ def plane_of(params, z):
     return np.clip(c, 0, params.full_cells_z - 1).astype(np.int64)
 
 
-def plan_cuts(params, z, world, min_planes=2 * HALO):
-    """Cut planes [c0=0, c1, ..., c_world=nz] that balance the particle count per slab.
-
-    Every slab gets at least `min_planes` planes (a slab must be at least as thick as the two
-    halos it feeds).  Deterministic: every rank computes the same cuts from the same z."""
-    nz = params.full_cells_z
+def cuts_from_histogram(hist, world, min_planes=2 * HALO):
+    """Cut planes [c0=0, c1, ..., c_world=nz] that balance the particle count per slab, from the
+    number of particles per z-plane.  Every slab gets at least `min_planes` planes (a slab must
+    be at least as thick as the two halos it feeds).  Deterministic."""
+    hist = np.asarray(hist, np.float64)
+    nz = hist.size
     if world * min_planes > nz:
         raise ValueError("grid has %d planes: too few for %d slabs of >= %d planes" %
                          (nz, world, min_planes))
-    hist = np.bincount(plane_of(params, z), minlength=nz).astype(np.float64)
     cum = np.concatenate([[0.0], np.cumsum(hist)])
     total = cum[-1]
     cuts = [0]
@@ -55,6 +54,13 @@ def plan_cuts(params, z, world, min_planes=2 * HALO):
         cuts.append(c)
     cuts.append(nz)
     return cuts
+
+
+def plan_cuts(params, z, world, min_planes=2 * HALO):
+    """cuts_from_histogram of the z coordinates `z`: every rank computes the same cuts from the
+    same z."""
+    hist = np.bincount(plane_of(params, z), minlength=params.full_cells_z)
+    return cuts_from_histogram(hist, world, min_planes)
 
 
 def message_bytes(capacity_records):
@@ -79,6 +85,9 @@ class HipSlab:
         self.params = params.copy()
         self.plane_lo, self.plane_hi = int(plane_lo), int(plane_hi)
         self.capacity, self.msg_capacity = int(capacity), int(msg_capacity)
+        # records a message may hold right now (<= msg_capacity, what the buffers can take): what
+        # the pack kernels enforce and what the transport moves - see trim_messages()
+        self.msg_active = self.msg_capacity
         self.device = torch.device("cuda", device)
         rc = self._lib.sph_hip_create_slab(C.byref(self._ctx), C.byref(self.params), self.capacity,
                                            int(device), self.plane_lo, self.plane_hi)
@@ -124,6 +133,7 @@ class HipSlab:
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1)
         vel = np.ascontiguousarray(vel, np.float32).reshape(-1)
         mass = np.ascontiguousarray(mass, np.float32)
+        self.all_masses_equal = bool(all_masses_equal)
         self._check(self._lib.sph_hip_slab_upload(self._ctx, ids.size, _ptr(pos), _ptr(vel),
                                                   _ptr(mass), _ptr(ids), int(all_masses_equal)),
                     "sph_hip_slab_upload")
@@ -134,14 +144,14 @@ class HipSlab:
 
     def pack(self):
         self._check(self._lib.sph_hip_slab_pack(self._ctx, self._dp(self.send_left),
-                                                self._dp(self.send_right), self.msg_capacity),
+                                                self._dp(self.send_right), self.msg_active),
                     "sph_hip_slab_pack")
 
     def unpack(self, recv_left=None, recv_right=None):
         left = recv_left if recv_left is not None else self.recv_left
         right = recv_right if recv_right is not None else self.recv_right
         self._check(self._lib.sph_hip_slab_unpack(self._ctx, self._dp(left), self._dp(right),
-                                                  self.msg_capacity), "sph_hip_slab_unpack")
+                                                  self.msg_active), "sph_hip_slab_unpack")
 
     def step(self):
         self._check(self._lib.sph_hip_step(self._ctx), "sph_hip_step")
@@ -152,7 +162,7 @@ class HipSlab:
         transport will run on; the border work is enqueued there (None: the slab's stream)."""
         ptr = C.c_void_p(exchange_stream.cuda_stream) if exchange_stream is not None else None
         self._check(self._lib.sph_hip_slab_step_begin(self._ctx, self._dp(self.send_left),
-                                                      self._dp(self.send_right), self.msg_capacity,
+                                                      self._dp(self.send_right), self.msg_active,
                                                       ptr),
                     "sph_hip_slab_step_begin")
 
@@ -173,11 +183,37 @@ class HipSlab:
         """`steps` steps with the overlapped neighbour exchange, all enqueued by the library."""
         self._check(self._lib.sph_hip_slab_comm_run(self._ctx, int(steps)), "sph_hip_slab_comm_run")
 
+    def comm_trim(self, slack=1.25, extra=1024):
+        """Native exchange: agree on the message size from what was packed last
+        (sph_hip_slab_comm_trim; collective, synchronises)."""
+        n = C.c_int32()
+        self._check(self._lib.sph_hip_slab_comm_trim(self._ctx, float(slack), int(extra), C.byref(n)),
+                    "sph_hip_slab_comm_trim")
+        self.msg_active = n.value
+        return n.value
+
     def comm_selftest(self):
         self._check(self._lib.sph_hip_slab_comm_selftest(self._ctx), "sph_hip_slab_comm_selftest")
 
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
+
+    def send_counts(self):
+        """Records in the two messages packed last (synchronises the slab's stream)."""
+        self.stream.synchronize()
+        out = []
+        for m in (self.send_left, self.send_right):
+            out.append(int(m[:4].view(self._torch.int32)[0].item()) if m is not None else 0)
+        return tuple(out)
+
+    def download_mass(self):
+        """Masses of the owned particles, in the row order of download()."""
+        cap = self.capacity
+        mass = np.zeros(cap, np.float32)
+        rows = C.c_int32()
+        self._check(self._lib.sph_hip_slab_download_mass(self._ctx, cap, C.byref(rows), _ptr(mass)),
+                    "sph_hip_slab_download_mass")
+        return mass[:rows.value]
 
     def poll_errors(self):
         """Non-blocking look at the exchange's error bits (sph_hip_slab_poll_errors): raises
@@ -286,6 +322,9 @@ class NativeSlabStepper:
     def run(self, steps):
         self.slab.comm_run(steps)
 
+    def trim_messages(self, slack=1.25, extra=1024):
+        return self.slab.comm_trim(slack, extra)
+
 
 class DistTransport:
     """Neighbour exchange over torch.distributed point-to-point ops (RCCL when the backend is
@@ -312,16 +351,23 @@ class DistTransport:
         return ops
 
     def _build_ops(self, slab):
+        # only the part of a message buffer that can hold records right now travels
+        # (slab.msg_active <= msg_capacity, agreed by all ranks in trim_messages)
         dist = self.dist
+        nbytes = message_bytes(getattr(slab, "msg_active", slab.msg_capacity))
         ops = []
         left, right = self.rank - 1, self.rank + 1
         if left >= 0:
-            ops.append(dist.P2POp(dist.isend, slab.send_left, left, self.group))
-            ops.append(dist.P2POp(dist.irecv, slab.recv_left, left, self.group))
+            ops.append(dist.P2POp(dist.isend, slab.send_left[:nbytes], left, self.group))
+            ops.append(dist.P2POp(dist.irecv, slab.recv_left[:nbytes], left, self.group))
         if right < self.world:
-            ops.append(dist.P2POp(dist.isend, slab.send_right, right, self.group))
-            ops.append(dist.P2POp(dist.irecv, slab.recv_right, right, self.group))
+            ops.append(dist.P2POp(dist.isend, slab.send_right[:nbytes], right, self.group))
+            ops.append(dist.P2POp(dist.irecv, slab.recv_right[:nbytes], right, self.group))
         return ops
+
+    def forget(self):
+        """The slab or its active message size changed: rebuild the op list."""
+        self._op_cache = None
 
     def _run(self, ops):
         if ops:
@@ -385,9 +431,11 @@ class HostStagedTransport(DistTransport):
         import torch
         dist = self.dist
         left, right = self.rank - 1, self.rank + 1
+        nbytes = message_bytes(getattr(slab, "msg_active", slab.msg_capacity))
         with torch.cuda.stream(slab.stream):
-            sends = {k: (getattr(slab, "send_" + k).cpu() if getattr(slab, "send_" + k) is not None
-                         else None) for k in ("left", "right")}
+            sends = {k: (getattr(slab, "send_" + k)[:nbytes].cpu()
+                         if getattr(slab, "send_" + k) is not None else None)
+                     for k in ("left", "right")}
         slab.stream.synchronize()
         recvs = {k: (torch.empty_like(v) if v is not None else None) for k, v in sends.items()}
         ops = []
@@ -403,7 +451,7 @@ class HostStagedTransport(DistTransport):
         with torch.cuda.stream(slab.stream):
             for k in ("left", "right"):
                 if recvs[k] is not None:
-                    getattr(slab, "recv_" + k).copy_(recvs[k], non_blocking=False)
+                    getattr(slab, "recv_" + k)[:nbytes].copy_(recvs[k], non_blocking=False)
 
 
 class DistSlabStepper:
@@ -419,9 +467,18 @@ class DistSlabStepper:
 
     CHECK_EVERY = 16     # steps between two looks at the slab's error bits (no synchronisation)
 
-    def __init__(self, slab, transport, overlap=True):
+    def __init__(self, slab, transport, overlap=True, make_slab=None, cuts=None,
+                 rebalance_every=0, imbalance=1.1, trim_every=0):
+        """make_slab(cuts, rank, plane_histogram) -> a new, empty slab for planes
+        [cuts[rank], cuts[rank + 1]): needed for rebalance() (with `cuts`, the current ones).
+        rebalance_every / trim_every: steps between collective re-evaluations of the cut planes
+        (when the fullest slab holds more than `imbalance` x the mean) and of the message size
+        (0 = never; both synchronise the ranks, so hundreds of steps apart)."""
         self.slab, self.transport = slab, transport
         self.overlap = overlap and hasattr(slab, "step_begin")
+        self.make_slab, self.cuts = make_slab, (list(cuts) if cuts is not None else None)
+        self.rebalance_every, self.imbalance, self.trim_every = rebalance_every, imbalance, trim_every
+        self.rebalances = 0
         self._primed = False
         self._steps = 0
 
@@ -429,12 +486,123 @@ class DistSlabStepper:
         for _ in range(steps):
             self.step()
 
+    # ---- collectives between steps (every rank calls them at the same step) --------------------
+    def _device(self):
+        """where this process group wants its tensors (RCCL: the slab's GPU; gloo: host)"""
+        dist = self.transport.dist
+        backend = dist.get_backend(self.transport.group)
+        return self.slab.device if backend == "nccl" and hasattr(self.slab, "device") else "cpu"
+
+    def trim_messages(self, slack=1.25, extra=1024):
+        """Only the used part of a halo message needs to cross the link: the buffers are sized
+        generously once (slab_capacities), but the records actually packed are far fewer - 1.4 MB
+        of 3.2 MB in the 4M-particle benchmark.  Every rank looks at the messages it packed last,
+        the largest count (x slack + extra records of head room) becomes the size every message
+        is packed for, sent and received with from now on; a message that outgrows it raises the
+        overflow bit, which stops the run (poll_errors) - call this again then, or periodically
+        (trim_every).  Collective; synchronises."""
+        import torch
+        dist, slab = self.transport.dist, self.slab
+        if not hasattr(slab, "send_counts"):
+            return slab.msg_capacity
+        want = min(slab.msg_capacity, int(max(slab.send_counts()) * slack) + extra)
+        t = torch.tensor([want], dtype=torch.int64, device=self._device())
+        if self.transport.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.transport.group)
+        slab.msg_active = int(t.item())
+        self.transport.forget()
+        return slab.msg_active
+
+    def rebalance(self, force=False):
+        """Re-evaluate the cut planes from the current distribution of the particles along z and
+        move the particles whose plane changed owner (cuts "re-evaluated
+        periodically").  The state itself moves unchanged - ids, positions, velocities, masses - so
+        the run continues bit for bit as if the cuts had always been there.  Collective and
+        host-staged (download, point-to-point exchange of the rows that change owner, upload into a
+        new slab): meant for every few hundred steps.  Returns True if the cuts changed."""
+        import torch
+        dist, tr, slab = self.transport.dist, self.transport, self.slab
+        rank, world, group = tr.rank, tr.world, tr.group
+        if world == 1 or self.make_slab is None or self.cuts is None:
+            return False
+        dev = self._device()
+        owned = torch.tensor([slab.status()["owned"]], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(owned) for _ in range(world)]
+        dist.all_gather(every, owned, group=group)
+        counts = np.array([int(t.item()) for t in every], np.float64)
+        if not force and counts.max() <= self.imbalance * counts.mean():
+            return False
+        d = slab.download()
+        mass = slab.download_mass()
+        pos3 = d["pos"].reshape(-1, 3)
+        planes = plane_of(slab.params, pos3[:, 2])
+        nz = slab.params.full_cells_z
+        hist = torch.from_numpy(np.bincount(planes, minlength=nz).astype(np.int64)).to(dev)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        hist = hist.cpu().numpy()
+        new_cuts = cuts_from_histogram(hist, world)
+        if new_cuts == self.cuts:
+            return False
+        # rows {x, y, z, m, vx, vy, vz, id bits} by new owner
+        rows = np.empty((mass.size, 8), np.float32)
+        rows[:, 0:3] = pos3
+        rows[:, 3] = mass
+        rows[:, 4:7] = d["vel"].reshape(-1, 3)
+        rows[:, 7] = d["ids"].view(np.float32)
+        dest = np.searchsorted(np.asarray(new_cuts[1:], np.int64), planes, side="right")
+        out = [np.ascontiguousarray(rows[dest == r]) for r in range(world)]
+        mine = torch.tensor([o.shape[0] for o in out], dtype=torch.int64, device=dev)
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine, group=group)          # table[s][r] = rows s sends to r
+        ops, inbox, keep_alive = [], {}, []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            if out[peer].shape[0]:
+                t = torch.from_numpy(out[peer]).to(dev)
+                keep_alive.append(t)
+                ops.append(dist.P2POp(dist.isend, t, peer, group))
+            n_in = int(table[peer][rank].item())
+            if n_in:
+                inbox[peer] = torch.empty((n_in, 8), dtype=torch.float32, device=dev)
+                ops.append(dist.P2POp(dist.irecv, inbox[peer], peer, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        parts = [out[rank]] + [inbox[k].cpu().numpy() for k in sorted(inbox)]
+        rows = np.concatenate(parts) if len(parts) > 1 else parts[0]
+        rows = rows[np.argsort(rows[:, 7].copy().view(np.uint32), kind="stable")]
+        new_slab = self.make_slab(new_cuts, rank, hist)
+        new_slab.upload(np.ascontiguousarray(rows[:, 7]).view(np.uint32),
+                        np.ascontiguousarray(rows[:, 0:3]).reshape(-1),
+                        np.ascontiguousarray(rows[:, 4:7]).reshape(-1),
+                        np.ascontiguousarray(rows[:, 3]),
+                        all_masses_equal=bool(getattr(slab, "all_masses_equal", False)))
+        # the message size the ranks agreed on stays in force (all of them carry it over alike)
+        new_slab.msg_active = min(getattr(slab, "msg_active", new_slab.msg_capacity),
+                                  new_slab.msg_capacity)
+        if hasattr(slab, "close"):
+            slab.close()
+        self.slab, self.cuts = new_slab, list(new_cuts)
+        self._primed = False            # the new slabs have no ghosts yet
+        tr.forget()
+        self.rebalances += 1
+        return True
+
     def step(self):
         slab, tr = self.slab, self.transport
         # fail loudly: a run that has lost particles (message or capacity overflow, a particle the
         # early exchange missed) stops within 2 * CHECK_EVERY steps instead of running on
         if self._steps % self.CHECK_EVERY == 0 and hasattr(slab, "poll_errors"):
             slab.poll_errors()
+        if self._steps > 0:
+            if self.rebalance_every and self._steps % self.rebalance_every == 0:
+                if self.rebalance():
+                    slab = self.slab
+            if self.trim_every and self._steps % self.trim_every == 0:
+                self.trim_messages()
         self._steps += 1
         if not self.overlap:
             slab.pack()

@@ -15,7 +15,8 @@ class FakeSlab:
     def __init__(self, oracle, oparams, plane_lo, plane_hi, msg_capacity, has_left, has_right):
         self.o, self.p = oracle, oparams
         self.plane_lo, self.plane_hi = plane_lo, plane_hi
-        self.msg_capacity = msg_capacity
+        self.msg_capacity = self.msg_active = msg_capacity
+        self.params = oparams
         nbytes = message_bytes(msg_capacity)
         mk = lambda on: torch.zeros(nbytes, dtype=torch.uint8) if on else None
         self.send_left, self.send_right = mk(has_left), mk(has_right)
@@ -26,6 +27,7 @@ class FakeSlab:
         self.errors = 0
 
     def upload(self, ids, pos, vel, mass, all_masses_equal):
+        self.all_masses_equal = bool(all_masses_equal)
         self.owned = dict(ids=np.asarray(ids, np.uint32).copy(),
                           pos=np.asarray(pos, np.float32).reshape(-1, 3).copy(),
                           vel=np.asarray(vel, np.float32).reshape(-1, 3).copy(),
@@ -49,9 +51,9 @@ class FakeSlab:
         o = self.owned
         pl = plane_of(self.p, o["pos"][:, 2])
         if self.send_left is not None:
-            self._write(self.send_left, pl < self.plane_lo + HALO, o, self.msg_capacity)
+            self._write(self.send_left, pl < self.plane_lo + HALO, o, self.msg_active)
         if self.send_right is not None:
-            self._write(self.send_right, pl >= self.plane_hi - HALO, o, self.msg_capacity)
+            self._write(self.send_right, pl >= self.plane_hi - HALO, o, self.msg_active)
         keep = (pl >= self.plane_lo) & (pl < self.plane_hi)
         if self.send_left is None:
             assert (pl >= self.plane_lo).all()
@@ -107,7 +109,8 @@ class FakeSlab:
         # what download() returns: the particles this slab owned during the step (as the HIP slab,
         # whose owned range is that of the step's cell build)
         self.last = dict(ids=self.owned["ids"].copy(), pos=self.owned["pos"].copy(),
-                         vel=self.owned["vel"].copy(), rho=out["rho"][sel],
+                         vel=self.owned["vel"].copy(), mass=self.owned["mass"].copy(),
+                         rho=out["rho"][sel],
                          acc=out["acc"].reshape(-1, 3)[sel], ncount=out["ncount"][sel])
         self.ghosts = None
 
@@ -124,6 +127,13 @@ class FakeSlab:
         l = self.last
         return dict(ids=l["ids"], pos=l["pos"].reshape(-1), vel=l["vel"].reshape(-1),
                     rho=l["rho"], acc=l["acc"].reshape(-1), ncount=l["ncount"])
+
+    def download_mass(self):
+        return self.last["mass"]
+
+    def send_counts(self):
+        return tuple(int(m.numpy()[:4].view(np.int32)[0]) if m is not None else 0
+                     for m in (self.send_left, self.send_right))
 
     def status(self):
         return dict(live=0, owned=int(self.owned["ids"].size), errors=self.errors)

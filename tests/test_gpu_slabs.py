@@ -4,6 +4,8 @@ their messages over by pointer (LocalSlabGroup) — kernels, message format and 
 protocol are exactly those of the distributed run; only the transport differs (that part is
 covered under gloo in test_slab_cpu.py).  Bar: bit-identical per-particle results for any
 number of slabs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -249,3 +251,87 @@ def test_native_rccl_exchange_single_rank(oracle, hiplib):
     assert np.array_equal(d["acc"].reshape(-1, 3), ref["acc"].reshape(-1, 3)[ids])
     assert np.array_equal(d["rho"], ref["rho"][ids])
     s.close()
+
+
+def _gpu_rebalance_worker(rank, world, port, steps, outdir):
+    """one process per slab, both on GPU 0 (gloo + host-staged messages: RCCL refuses two ranks on
+    one device); everything else - HipSlab, kernels, message format, stepper - as on a node"""
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import smoothed_particle_hydrodynamics_amd as S
+        from smoothed_particle_hydrodynamics_amd import scenes
+        from smoothed_particle_hydrodynamics_amd import slab as SL
+        torch.cuda.set_device(0)
+        p, pos, vel, mass = scenes.dense_block(40000, lo=(1.0, 1.0, 0.6), hi=(2.0, 2.0, 2.4), seed=17,
+                                               speed=10.0)
+        vel = vel.copy()
+        vel.reshape(-1, 3)[:, 2] += np.float32(80.0)      # the block drifts up the slab axis
+        mass = (0.5 + scenes.uniform01(19, np.arange(mass.size))).astype(np.float32)
+        z = pos.reshape(-1, 3)[:, 2]
+        cuts = SL.plan_cuts(p, z, world)
+
+        def make_slab(new_cuts, r, hist):
+            return SL.HipSlab(p, new_cuts[r], new_cuts[r + 1], 60000, 20000, device=0,
+                              has_left=r > 0, has_right=r + 1 < world)
+
+        slab = make_slab(cuts, rank, None)
+        slab.upload(*SL.split_scene(p, cuts, rank, pos, vel, mass), all_masses_equal=False)
+        stepper = SL.DistSlabStepper(slab, SL.HostStagedTransport(rank, world), make_slab=make_slab,
+                                     cuts=cuts, rebalance_every=4, imbalance=1.02, trim_every=3)
+        for _ in range(steps):
+            stepper.step()
+        slab = stepper.slab
+        slab.synchronize()
+        d = slab.download()
+        assert slab.status()["errors"] == 0
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), cuts0=np.array(cuts),
+                 cuts=np.array(stepper.cuts), rebalances=stepper.rebalances,
+                 active=slab.msg_active, **d)
+        slab.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rebalancing_and_trimmed_messages_on_the_gpu(hiplib, tmp_path):
+    """Two slab processes on the one GPU, a scene that drifts along z: cuts re-evaluated every 4
+    steps (download incl. masses, rows that change owner exchanged, new slab contexts), message
+    size agreed every 3 steps from what was packed (the pack kernels enforce it, the transport moves
+    only that part): per-particle results after 10 steps equal the single context's, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    steps, world = 10, 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_gpu_rebalance_worker, args=(world, port, steps, str(tmp_path)), nprocs=world, join=True)
+    p, pos, vel, mass = scenes.dense_block(40000, lo=(1.0, 1.0, 0.6), hi=(2.0, 2.0, 2.4), seed=17,
+                                           speed=10.0)
+    vel = vel.copy()
+    vel.reshape(-1, 3)[:, 2] += np.float32(80.0)
+    mass = (0.5 + scenes.uniform01(19, np.arange(mass.size))).astype(np.float32)
+    with S.SPH(mass.size, p) as one:
+        one.setParticles(pos, vel, mass)
+        one.run(steps)
+        part = one.getParticles()
+    seen = np.zeros(mass.size, bool)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        ids = d["ids"].astype(np.int64)
+        assert not seen[ids].any()
+        seen[ids] = True
+        assert np.array_equal(d["pos"].reshape(-1, 3), part.mPosition.reshape(-1, 3)[ids])
+        assert np.array_equal(d["vel"].reshape(-1, 3), part.mVelocity.reshape(-1, 3)[ids])
+        assert np.array_equal(d["rho"], part.mDensity[ids])
+        assert np.array_equal(d["acc"].reshape(-1, 3), part.mAcceleration.reshape(-1, 3)[ids])
+        assert np.array_equal(d["ncount"], part.mNeighborCount[ids])
+        assert int(d["rebalances"]) >= 1 and (d["cuts"] != d["cuts0"]).any()
+        assert int(d["active"]) < 20000
+    assert seen.all()

@@ -123,6 +123,89 @@ def test_distributed_slabs_equal_single_domain(oracle, tmp_path, world, overlap)
     assert migrated > 0, "the scene is meant to move particles across the cuts"
 
 
+def drifting_scene(n=5000):
+    """a block that moves up the z axis as a whole (plus some random motion): the balanced cuts
+    of step 0 are far from balanced a few steps later"""
+    pos = box_fill(n, (1.0, 1.0, 0.6), (2.0, 2.0, 2.2), 17)
+    vel = box_fill(n, (-10.0,) * 3, (10.0,) * 3, 18)
+    vel.reshape(-1, 3)[:, 2] += np.float32(90.0)        # ~0.9 cell planes per step
+    mass = (0.5 + box_fill(n, (0,) * 3, (1,) * 3, 19)[:n]).astype(np.float32)
+    return pos, vel, mass
+
+
+def _worker_rebalance(rank, world, port, steps, outdir, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle
+        from fake_slab import FakeSlab
+        from smoothed_particle_hydrodynamics_amd.slab import (DistSlabStepper, DistTransport,
+                                                              plan_cuts, split_scene)
+        o = Oracle()
+        p = o.params_for_h(0.1)
+        pos, vel, mass = drifting_scene()
+        cuts = plan_cuts(p, pos.reshape(-1, 3)[:, 2], world)
+
+        def make_slab(new_cuts, r, hist):
+            return FakeSlab(o, p, new_cuts[r], new_cuts[r + 1], 8192, r > 0, r + 1 < world)
+
+        slab = make_slab(cuts, rank, None)
+        slab.upload(*split_scene(p, cuts, rank, pos, vel, mass), all_masses_equal=False)
+        stepper = DistSlabStepper(slab, DistTransport(rank, world), overlap=overlap,
+                                  make_slab=make_slab, cuts=cuts, rebalance_every=3, imbalance=1.02,
+                                  trim_every=4)
+        history, active = [list(cuts)], []
+        for _ in range(steps):
+            stepper.step()
+            history.append(list(stepper.cuts))
+            active.append(stepper.slab.msg_active)
+        d = stepper.slab.download()
+        assert stepper.slab.status()["errors"] == 0
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), cuts=np.array(history),
+                 rebalances=stepper.rebalances, active=np.array(active), **d)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True], ids=["serial", "early-exchange"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_cut_rebalancing_and_message_trimming_keep_the_bits(oracle, tmp_path, world, overlap):
+    """A scene that drifts along the slab axis: every 3 steps the ranks re-evaluate the cut planes
+    from the z-plane histogram and move the particles that change owner, every 4 steps they agree
+    on a smaller message size from what was actually packed.  Neither may change a single bit of
+    any particle with respect to the single-domain run (cuts re-evaluated
+    periodically; results independent of the rank count)."""
+    steps = 10
+    port = _free_port()
+    mp.spawn(_worker_rebalance, args=(world, port, steps, str(tmp_path), overlap), nprocs=world,
+             join=True)
+    p = oracle.params_for_h(0.1)
+    pos, vel, mass = drifting_scene()
+    n = mass.size
+    for _ in range(steps):
+        ref = oracle.step(p, pos, vel, mass, mode="full")
+    seen = np.zeros(n, bool)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        ids = d["ids"].astype(np.int64)
+        assert not seen[ids].any()
+        seen[ids] = True
+        assert np.array_equal(d["pos"].reshape(-1, 3), pos.reshape(-1, 3)[ids])
+        assert np.array_equal(d["vel"].reshape(-1, 3), vel.reshape(-1, 3)[ids])
+        assert np.array_equal(d["rho"], ref["rho"][ids])
+        assert np.array_equal(d["acc"].reshape(-1, 3), ref["acc"].reshape(-1, 3)[ids])
+        assert np.array_equal(d["ncount"], ref["ncount"][ids])
+        cuts = d["cuts"]
+        assert int(d["rebalances"]) >= 2, "the drifting block must have moved the cuts"
+        assert (cuts[-1] != cuts[0]).any() and (np.diff(cuts, axis=1) >= 4).all()
+        assert d["active"][-1] < 8192 and d["active"][0] == 8192     # trimmed after step 4
+        if r == 0:
+            first = cuts
+        assert np.array_equal(cuts, first)                           # every rank agrees
+    assert seen.all()
+
+
 def test_scene_subsets_match_the_whole_scene():
     """bench.py's ranks generate only their own slab: any coordinate axis or subset of rows of the
     counter-based scene must equal the corresponding part of the whole scene, and the parameters
