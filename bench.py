@@ -6,8 +6,11 @@
 
 A "step" is one pass of the hot path (cell build + density + acceleration + integrate,
 FULL neighbour mode) over the whole particle set, state resident in HBM.  Prints ONE JSON
-line (rank 0).  See DESIGN.md §Measurement for the definitions used in `roofline` and
-`cpu_baseline`.
+line (rank 0).  N = 1: the 4 194 304-particle column (BASELINE configs[2]).  N > 1: strong
+scaling of the 16 777 216-particle column (configs[3]) over N z-slabs, with rank 0's
+single-context time of the same scene (`strong_scaling`) and the 67 108 864-particle 8:1:1
+channel (configs[4]) as `other_scaling`.  See DESIGN.md §Measurement for the definitions used
+in `roofline` and `cpu_baseline`.
 """
 import argparse
 import json

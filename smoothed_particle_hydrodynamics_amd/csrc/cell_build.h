@@ -24,7 +24,7 @@
 #define RANK_BIG 512
 #endif
 #define RANK_CHUNK 4096   // members sorted at a time in LDS (key + source index: 32 KiB)
-#define RANK_BIG_BLOCKS 256
+#define RANK_BIG_BLOCKS 64
 #define SCAN_ITEMS 16
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
