@@ -4,7 +4,8 @@
 // reference appends particle indices to one QList per voxel in a serial loop, so every voxel
 // list is in ascending particle index.  Here:
 //   1. k_hash_count   cell id per particle, arrival slot from one counting atomic per cell run
-//   2. k_scan_*       exclusive scan of the per-cell counts (wave64 shuffles + LDS carries)
+//   2. k_scan_*       exclusive scan of the per-cell counts (wave64 shuffles + LDS carries; two
+//                     launches: tile totals, then the scan with each tile's carry summed on the fly)
 //   3. k_scatter      cell-sorted permutation (arbitrary order inside a cell)
 //   4. k_rank_*       order inside each cell fixed to ascending particle index — the same
 //                     lists the reference builds, independent of atomic arrival order
@@ -159,22 +160,10 @@ k_scan_reduce(const uint32_t* __restrict__ count, int ncells, uint32_t* __restri
    if (threadIdx.x == 0) part[blockIdx.x] = total;
 }
 
-// one block: exclusive scan of the tile totals in place
-__global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_parts(uint32_t* __restrict__ part, int ntiles)
-{
-   uint32_t carry = 0;
-   for (int base = 0; base < ntiles; base += SCAN_THREADS) {
-      const int idx = base + threadIdx.x;
-      const uint32_t v = idx < ntiles ? part[idx] : 0u;
-      uint32_t total;
-      const uint32_t ex = block_exclusive_scan(v, &total);
-      if (idx < ntiles) part[idx] = carry + ex;
-      carry += total;
-   }
-}
-
-// writes cell_start[0..ncells] and clears the counts for the next build
+// writes cell_start[0..ncells] and clears the counts for the next build.  The carry into a tile is
+// the sum of the totals of the tiles before it (k_scan_reduce wrote them): every workgroup adds
+// them up itself - a few KB out of L2 - instead of waiting for a one-workgroup scan launch of its
+// own between the two kernels.
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restrict__ part,
              uint32_t* __restrict__ cell_start, uint32_t* __restrict__ big_cells)
@@ -199,8 +188,12 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
    }
 #pragma unroll
    for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+   uint32_t before = 0;
+   for (int t = threadIdx.x; t < (int)blockIdx.x; t += SCAN_THREADS) before += part[t];
+   uint32_t carry;
+   block_exclusive_scan(before, &carry);   // carry = sum over the workgroup = totals of all earlier tiles
    uint32_t total;
-   uint32_t run = part[blockIdx.x] + block_exclusive_scan(s, &total);
+   uint32_t run = carry + block_exclusive_scan(s, &total);
    if (base + SCAN_ITEMS <= ncells) {
       uint4* o = reinterpret_cast<uint4*>(cell_start + base);
       uint4* z = reinterpret_cast<uint4*>(count + base);

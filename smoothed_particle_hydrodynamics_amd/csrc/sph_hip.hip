@@ -330,7 +330,6 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    const int ncells_scan = g.ncells + 1;
    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
                       ncells_scan, ctx->scan_part);
-   hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(SCAN_THREADS), 0, st, ctx->scan_part, tiles);
    hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
                       ncells_scan, ctx->scan_part, ctx->cell_start, ctx->big_cells);
    // sorted ranges: owned planes [lo, hi), density planes one wider (clipped to what is held)
