@@ -25,6 +25,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PAIR_SAMPLE_EVERY = 5          # the density+acceleration pair is timed (two HIP events, ~10 us of
+                               # stream time each) on every 5th step of the timed region
 DENSITY_FORCE_BYTES = 64       # algorithmic bytes per particle of the density+force pass
                                # (density 20 B + force 44 B)
 
@@ -184,14 +186,14 @@ def run_single(args, S, scenes, torch, local_rank):
     sph = S.SPH(n, p, mode=S.MODE_FULL, device=local_rank)
     sph.setParticles(pos, vel, mass)
     # Timed region: HIP events (on the context's stream) bracket only the density+acceleration
-    # pair of every step - each event record costs ~10 us of stream time, so the full per-phase
-    # split is taken over a few extra steps after the timed region.
+    # pair, and only on every PAIR_SAMPLE_EVERY-th step - each event record costs ~10 us of stream
+    # time; the full per-phase split is taken over a few extra steps after the timed region.
     sph.setTiming(S.TIMING_SUMS)
     for _ in range(args.warmup):
         sph.step()
     sph.synchronize()
     torch.cuda.synchronize()
-    sph.resetTimings()
+    sph.setTimingStride(PAIR_SAMPLE_EVERY)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sph.step()
@@ -199,6 +201,7 @@ def run_single(args, S, scenes, torch, local_rank):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pair, covered = sph.phaseTotals()
+    sph.setTimingStride(1)
     totals = phase_split(sph, S, lambda: sph.step(), sph.synchronize, sph.setTiming, sph.phaseTotals)
     totals["pair_ms"] = pair[2] / covered
     nb_mean = float(sph.getParticles().mNeighborCount.mean())
@@ -271,7 +274,7 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     # from here on only the used part of the halo messages crosses the links (+25 % head room)
     msg_records = stepper.trim_messages() if warmup > 0 else slab.msg_capacity
     fence()
-    slab.reset_timings()
+    slab.set_timing_stride(PAIR_SAMPLE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         stepper.step()
@@ -290,6 +293,7 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
         raise SystemExit("slab run inconsistent: error bits %d, owned %d of %d" %
                          (int(err.item()), int(own.item()), n))
     pair, covered = slab.phase_totals()
+    slab.set_timing_stride(1)
     totals = phase_split(slab, S, stepper.step, fence, slab.set_timing, slab.phase_totals)
     totals["pair_ms"] = pair[2] / covered
     d = slab.download()
@@ -500,6 +504,7 @@ def main():
                 "bytes_per_particle": DENSITY_FORCE_BYTES,
                 "particles_per_launch": n_rank,
                 "ms_per_launch_pair": df_ms,
+                "launch_pairs_timed": covered,
                 "note": "VALU-bound gather-sum: see DESIGN.md (Roofline); frac is against the "
                         "64 B/particle compulsory-traffic figure of SURVEY.md 8(d)",
             },

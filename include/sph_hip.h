@@ -197,6 +197,10 @@ int sph_hip_reset_timings(sph_hip_context* ctx);
 #define SPH_HIP_TIMING_SUMS 1
 #define SPH_HIP_TIMING_PHASES 2
 int sph_hip_set_timing(sph_hip_context* ctx, int level);
+/* Record the events of the chosen level on every `every`-th timed step only (default 1 = every
+ * step); the totals and their step count then cover the sampled steps.  For measurements that
+ * must not weigh on what they measure (bench.py).  Resets the collected timings. */
+int sph_hip_set_timing_stride(sph_hip_context* ctx, int every);
 
 /* FULL mode, tiled kernels: statistics of the LDS tiles of the last step (synchronises).
  * out[0..11]: workgroups whose tile exceeds capacity level i (the levels are the largest tiles

@@ -160,6 +160,9 @@ struct sph_hip_context {
    hipEvent_t ev_density = nullptr; // early exchange: density done (main stream) -> border work may start
    hipEvent_t ev_border = nullptr;  //                 border acceleration done (exchange stream) -> integrate may run
    int timing_level = 2;           // SPH_HIP_TIMING_*: which events sph_hip_step() records
+   int timing_stride = 1;          // ... on every timing_stride-th step only (sph_hip_set_timing_stride)
+   long long timing_seen = 0;      // timed steps since the stride was set
+   int slab_step_level = 0;        // level sph_hip_slab_step_begin chose for the step in progress
    // LDS tile capacity of the two tiled kernels: chosen per launch among the largest tiles that
    // still allow B workgroups per CU (levels, ascending), from the tile size recent steps needed
    // (tile_feedback: pinned host word the density kernel stores into; 0 = nothing known yet)

@@ -565,12 +565,22 @@ inline int phase_event(const sph_hip_context* ctx, int k)
    return k;
 }
 
+// Which events the step about to be enqueued records: the context's level on every
+// timing_stride-th timed step, nothing on the others (an event record is a barrier packet of
+// ~10 us on the stream: sampling keeps the measurement from weighing on what it measures).
+int next_step_level(sph_hip_context* ctx, bool timed)
+{
+   if (!timed || ctx->timing_level == SPH_HIP_TIMING_OFF) return SPH_HIP_TIMING_OFF;
+   const bool sample = (ctx->timing_seen++ % ctx->timing_stride) == 0;
+   return sample ? ctx->timing_level : SPH_HIP_TIMING_OFF;
+}
+
 int step_impl(sph_hip_context* ctx, bool timed)
 {
    int rc;
    hipStream_t st = ctx->stream;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
-   const int level = timed ? ctx->timing_level : SPH_HIP_TIMING_OFF;
+   const int level = next_step_level(ctx, timed);
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
    if (phases) SPH_TRY(hipEventRecord(ev[0], st));
    if ((rc = launch_cell_build(ctx))) return rc;
@@ -1311,7 +1321,7 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
    hipStream_t st = ctx->stream;
    hipStream_t side = exchange_stream ? (hipStream_t)exchange_stream : st;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
-   const int level = ctx->timing_level;
+   const int level = ctx->slab_step_level = next_step_level(ctx, true);
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
    if (phases) SPH_TRY(hipEventRecord(ev[0], st));
    if ((rc = launch_cell_build(ctx, left_device, right_device))) return rc;
@@ -1353,7 +1363,7 @@ int sph_hip_slab_step_end(sph_hip_context* ctx)
    }
    hipStream_t st = ctx->stream;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
-   const int level = ctx->timing_level;
+   const int level = ctx->slab_step_level;
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
    if ((rc = launch_accel(ctx, 2, st))) return rc;
    if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
@@ -1671,6 +1681,22 @@ int sph_hip_set_timing(sph_hip_context* ctx, int level)
    SPH_TRY(hipStreamSynchronize(ctx->stream));  // events of the old level are not read any more
    ctx->timing_level = level;
    ctx->ev_steps = 0;
+   ctx->timing_seen = 0;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_set_timing_stride(sph_hip_context* ctx, int every)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (every < 1) {
+      ctx->err = "sph_hip_set_timing_stride: every >= 1";
+      return SPH_HIP_ERR_INVALID;
+   }
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   ctx->timing_stride = every;
+   ctx->ev_steps = 0;
+   ctx->timing_seen = 0;
    return SPH_HIP_OK;
 }
 

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "sph_hip_get_phase_totals": (C.c_int, [_ctx, _P(C.c_double * 6), _P(C.c_int32)]),
     "sph_hip_reset_timings": (C.c_int, [_ctx]),
     "sph_hip_set_timing": (C.c_int, [_ctx, C.c_int]),
+    "sph_hip_set_timing_stride": (C.c_int, [_ctx, C.c_int]),
     "sph_hip_get_tile_stats": (C.c_int, [_ctx, _P(C.c_int32 * 20)]),
     "sph_hip_get_energy": (C.c_int, [_ctx, _P(C.c_float), _P(C.c_float)]),
     "sph_hip_get_neighbor_stats": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),

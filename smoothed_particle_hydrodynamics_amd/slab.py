@@ -254,6 +254,10 @@ class HipSlab:
     def set_timing(self, level):
         self._check(self._lib.sph_hip_set_timing(self._ctx, int(level)), "sph_hip_set_timing")
 
+    def set_timing_stride(self, every):
+        self._check(self._lib.sph_hip_set_timing_stride(self._ctx, int(every)),
+                    "sph_hip_set_timing_stride")
+
     def reset_timings(self):
         self._check(self._lib.sph_hip_reset_timings(self._ctx), "sph_hip_reset_timings")
 

@@ -273,6 +273,11 @@ class SPH:
         acceleration as one interval, in slot 2), TIMING_OFF.  Resets the collected timings."""
         self._check(self._lib.sph_hip_set_timing(self._ctx, int(level)), "sph_hip_set_timing")
 
+    def setTimingStride(self, every):
+        """Record the timing events on every `every`-th step() only (sph_hip_set_timing_stride)."""
+        self._check(self._lib.sph_hip_set_timing_stride(self._ctx, int(every)),
+                    "sph_hip_set_timing_stride")
+
     def tileStats(self):
         """dict of the last step's LDS-tile statistics (sph_hip_get_tile_stats)."""
         out = (C.c_int32 * 20)()
