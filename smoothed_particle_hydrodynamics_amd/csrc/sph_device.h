@@ -11,6 +11,7 @@
 
 #define SPH_WAVE 64
 #define EV_RING 128
+#define PACE_STEPS 16   // the host enqueues at most 2 * PACE_STEPS steps ahead of the device
 
 // ---- error plumbing -------------------------------------------------------------------
 #define SPH_TRY(expr)                                                                \
@@ -159,6 +160,8 @@ struct sph_hip_context {
    hipStream_t border_stream = nullptr; // stream the last step_begin put the border work on
    hipEvent_t ev_density = nullptr; // early exchange: density done (main stream) -> border work may start
    hipEvent_t ev_border = nullptr;  //                 border acceleration done (exchange stream) -> integrate may run
+   hipEvent_t ev_pace[2] = {nullptr, nullptr};  // recorded every PACE_STEPS steps (see pace_host)
+   long long steps_enqueued = 0;
    int timing_level = 2;           // SPH_HIP_TIMING_*: which events sph_hip_step() records
    int timing_stride = 1;          // ... on every timing_stride-th step only (sph_hip_set_timing_stride)
    long long timing_seen = 0;      // timed steps since the stride was set

@@ -112,6 +112,8 @@ void free_all(sph_hip_context* ctx)
       delete c;
       ctx->comm = nullptr;
    }
+   for (int k = 0; k < 2; k++)
+      if (ctx->ev_pace[k]) (void)hipEventDestroy(ctx->ev_pace[k]);
    if (ctx->ev_density) (void)hipEventDestroy(ctx->ev_density);
    if (ctx->ev_border) (void)hipEventDestroy(ctx->ev_border);
    if (ctx->tile_feedback) (void)hipHostFree(ctx->tile_feedback);
@@ -565,6 +567,23 @@ inline int phase_event(const sph_hip_context* ctx, int k)
    return k;
 }
 
+// Keeps the host from running arbitrarily far ahead of the device.  Launch parameters that follow
+// the scene - the LDS tile capacities, chosen from statistics the device writes into pinned memory
+// (tile_feedback) - are fixed when a step is ENQUEUED: a host that enqueues hundreds of steps at
+// once (sph_hip_run(500)) would pick them all from the state before the first one, and a scene that
+// compresses meanwhile ends up with nearly every workgroup on the untiled route.  Every PACE_STEPS
+// steps an event is recorded and the event of PACE_STEPS steps ago waited for: the device always has
+// at least PACE_STEPS steps queued (no bubble), the statistics are at most 2 * PACE_STEPS steps old.
+int pace_host(sph_hip_context* ctx)
+{
+   const long long k = ctx->steps_enqueued++;
+   if (k % PACE_STEPS != 0) return SPH_HIP_OK;
+   const int slot = (int)((k / PACE_STEPS) & 1);
+   if (k >= 2 * PACE_STEPS) SPH_TRY(hipEventSynchronize(ctx->ev_pace[slot]));   // recorded 2 * PACE_STEPS steps ago
+   SPH_TRY(hipEventRecord(ctx->ev_pace[slot], ctx->stream));
+   return SPH_HIP_OK;
+}
+
 // Which events the step about to be enqueued records: the context's level on every
 // timing_stride-th timed step, nothing on the others (an event record is a barrier packet of
 // ~10 us on the stream: sampling keeps the measurement from weighing on what it measures).
@@ -580,6 +599,7 @@ int step_impl(sph_hip_context* ctx, bool timed)
    int rc;
    hipStream_t st = ctx->stream;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
+   if ((rc = pace_host(ctx))) return rc;
    const int level = next_step_level(ctx, timed);
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
    if (phases) SPH_TRY(hipEventRecord(ev[0], st));
@@ -826,6 +846,7 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    ctx->stream = ctx->own_stream;
    ctx->ev = new hipEvent_t[EV_RING * 7]();
    for (int k = 0; k < EV_RING * 7; k++) CREATE_TRY(hipEventCreate(&ctx->ev[k]));
+   for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_pace[k], hipEventDisableTiming));
    const size_t cap = (size_t)capacity;
    const int nbuf = (mode == SPH_HIP_MODE_FULL) ? 2 : 1;
    for (int b = 0; b < nbuf; b++) {
@@ -1321,6 +1342,7 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
    hipStream_t st = ctx->stream;
    hipStream_t side = exchange_stream ? (hipStream_t)exchange_stream : st;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
+   if ((rc = pace_host(ctx))) return rc;
    const int level = ctx->slab_step_level = next_step_level(ctx, true);
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
    if (phases) SPH_TRY(hipEventRecord(ev[0], st));
