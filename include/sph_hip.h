@@ -207,7 +207,9 @@ int sph_hip_set_timing_stride(sph_hip_context* ctx, int every);
  * that allow a given number of workgroups per CU), out[12]: workgroups, out[13]: largest tile
  * (entries), out[14], out[15]: workgroups computed untiled in the density / acceleration pass,
  * out[16], out[17]: tile capacities the two passes were launched with, out[18]: 1 if the list
- * entries were in their wide format (a capacity above 4064), out[19]: 0. */
+ * entries were in their wide format (a capacity above 4064), out[19]: neighbours per particle the
+ * lists currently hold (starts at 254; doubled, up to 1022, when a step reports particles with
+ * more - those are computed without a list, slower, same results). */
 int sph_hip_get_tile_stats(sph_hip_context* ctx, int32_t out[20]);
 
 /* mKineticEnergyTotal / mPotentialEnergyTotal of the last integrate

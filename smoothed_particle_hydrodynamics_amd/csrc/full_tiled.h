@@ -46,19 +46,30 @@
 #define ACCEL_BLOCKS (TILE_THREADS == 256 ? 5 : 2)
 #endif
 // Neighbour lists handed from the density pass to the acceleration pass: per workgroup
-// NLIST_WORDS rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
-// reads/writes 256 contiguous bytes).  Only rows in use are ever touched.
+// list_rows(list_cap) rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
+// reads/writes 256 contiguous bytes).  Only rows in use are ever touched.  list_cap - the
+// neighbours per particle the lists hold - is a launch argument: a context starts with NLIST_CAP
+// and the host doubles it (up to NLIST_CAP_MAX, memory permitting) when the density pass reports
+// particles that went without a list; a breaking dam compresses to several hundred neighbours.
 #ifndef NLIST_CAP
-#define NLIST_CAP 254   // neighbours per particle the lists hold (a breaking dam compresses to > 100)
+#define NLIST_CAP 254
 #endif
-// two entries per 32-bit word: word r of a lane holds its entries 2r (low half) and 2r+1;
-// one spare word row swallows overflowing appends
-#define NLIST_WORDS (NLIST_CAP / 2 + 1)
-// first list word of a particle that has no list (more neighbours than NLIST_CAP): no valid
+#define NLIST_CAP_MAX 1022
+// two entries per 32-bit word: word r of a lane holds its entries 2r (low half) and 2r+1
+// (+ one spare row)
+__host__ __device__ __forceinline__ constexpr int list_rows(int list_cap) { return list_cap / 2 + 1; }
+// first list word of a particle that has no list (more neighbours than list_cap): no valid
 // entry has segment id 15
 #define NLIST_NO_LIST 0xffffffffu
-// bins of the neighbour-count histogram one lane of the scanning wave handles
-#define HIST_PER_LANE ((NLIST_CAP + 1 + SPH_WAVE - 1) / SPH_WAVE)
+// The acceleration pass deals its lanes by neighbour count through a histogram of HIST_BINS
+// bins: bin = min(count, list_cap) >> hist_shift(list_cap).
+#define HIST_BINS 256
+#define HIST_PER_LANE (HIST_BINS / SPH_WAVE)
+__host__ __device__ __forceinline__ constexpr int hist_shift(int list_cap)
+{
+   return list_cap < HIST_BINS ? 0 : (list_cap < 2 * HIST_BINS ? 1 : 2);
+}
+static_assert((NLIST_CAP_MAX >> hist_shift(NLIST_CAP_MAX)) < HIST_BINS && NLIST_CAP <= NLIST_CAP_MAX, "histogram bins");
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
 #ifndef DENSITY_UNROLL
 #define DENSITY_UNROLL 6
@@ -105,7 +116,7 @@ __device__ __forceinline__ f32x4 lds_read4(const float* base, int i)
    return *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + i, 16));
 }
 
-static_assert(DENSITY_UNROLL % 2 == 0 && ACCEL_UNROLL % 2 == 0 && NLIST_CAP % 2 == 0, "entries travel in pairs");
+static_assert(DENSITY_UNROLL % 2 == 0 && ACCEL_UNROLL % 2 == 0 && NLIST_CAP % 2 == 0 && NLIST_CAP_MAX % 2 == 0, "entries travel in pairs");
 static_assert(TILE_CAP_MAX + TILE_PAD <= (1 << ListEntry<false>::TBITS) &&
                  TILE_CAP_MAX_WIDE + TILE_PAD <= (1 << ListEntry<true>::TBITS),
               "tile index must fit the list entry");
@@ -359,8 +370,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                      float4* __restrict__ velB_out, float* __restrict__ auxc_out,
                      int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
                      uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
-                     int tile_cap, const int32_t* __restrict__ tile_stats,
-                     const uint32_t* __restrict__ giveup, int* __restrict__ tile_feedback)
+                     int tile_cap, int32_t* __restrict__ tile_stats,
+                     const uint32_t* __restrict__ giveup, int* __restrict__ tile_feedback, int list_cap)
 {
    __shared__ TileDesc sd;
    __shared__ int list_overflow;
@@ -370,7 +381,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    L.z = L.y + (tile_cap + TILE_PAD);
    // this step's tile statistics, for the host's next choice of capacity (plain stores to pinned
    // host memory; read there without synchronisation, only a hint)
-   if (blockIdx.x == 0 && threadIdx.x < TSTAT_COUNT) tile_feedback[threadIdx.x] = tile_stats[threadIdx.x];
+   // (TSTAT_NO_LIST is counted by this launch: the acceleration pass hands it over)
+   if (blockIdx.x == 0 && threadIdx.x < TSTAT_NO_LIST) tile_feedback[threadIdx.x] = tile_stats[threadIdx.x];
 
    const int begin = meta[META_SUM_BEGIN];
    const int end = meta[META_SUM_END];
@@ -414,7 +426,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const int self_t = p + sd.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
    // uniform base of the workgroup's list block; lanes address it with 32-bit offsets
-   uint32_t* list_block = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS);
+   uint32_t* list_block = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS);
 
    const float h2_screen = k.h2_screen;
    int count = 0;
@@ -454,9 +466,9 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             // a list that would overflow stops growing here (checked per chunk, not per entry):
             // the particle goes without a list anyway
             count += __builtin_popcount(mask);
-            if (count > NLIST_CAP) {
+            if (count > list_cap) {
                mask = 0u;
-               count = NLIST_CAP + 1;
+               count = list_cap + 1;
             }
          }
 #if defined(SPH_ABLATE) && SPH_ABLATE == 9
@@ -487,15 +499,20 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    // An odd count leaves the second half of the last word unwritten: zero it (a valid tile index).
    // The acceleration pass gathers by every entry of the words it fetches before it looks at the
    // count, and what an earlier step left there need not be an index of this step's tile.
-   if ((count & 1) && count < NLIST_CAP) my_entries[half] = (uint16_t)0;
+   if ((count & 1) && count < list_cap) my_entries[half] = (uint16_t)0;
    // A particle with more neighbours than its list holds (a scene many times denser than the
    // benchmark's) goes without a list: its lane walks its candidate ranges in the tile one by one
    // here - canonical order, small code - and again in the acceleration pass, which recognises it
    // by the marker in the list's first word; the other lanes of the workgroup keep their lists.
-   const bool overflowed = count > NLIST_CAP;
+   const bool overflowed = count > list_cap;
    if (overflowed) {
       list_overflow = 1;
       list_block[tid] = NLIST_NO_LIST;
+   }
+   if (__any(overflowed)) {
+      // reported to the host (through the acceleration pass), which then enlarges the lists
+      const int without = __popcll(__ballot(overflowed));
+      if ((tid & (SPH_WAVE - 1)) == 0) atomicAdd(&tile_stats[TSTAT_NO_LIST], without);
    }
    __syncthreads();
    if (tid == 0) nlist_overflow[wg] = list_overflow ? 2u : 0u;
@@ -606,10 +623,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // single neighbours up, so one ds_read_b128 per neighbour beats four scattered ds_read_b32.
 struct AccelLds {
    TileDesc desc;
-   int hist[HIST_PER_LANE * SPH_WAVE];  // neighbour-count histogram / its exclusive scan (NLIST_CAP+1 used)
+   int hist[HIST_BINS];            // neighbour-count histogram / its exclusive scan
    uint16_t perm[TILE_THREADS];    // lane -> list column, ascending neighbour count
 };
-static_assert(NLIST_CAP + 1 <= TILE_THREADS, "the histogram is cleared by one thread per bin");
+static_assert(HIST_BINS <= TILE_THREADS, "the histogram is cleared by one thread per bin");
 
 // The acceleration pass can be launched in two parts (early exchange): part 1 = the workgroups
 // that hold a particle of the owned planes next to a neighbouring slab (sorted ranges
@@ -634,7 +651,8 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                    float4* __restrict__ acc, const TileDesc* __restrict__ desc,
                    const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow,
                    int tile_cap, const int32_t* __restrict__ tile_stats,
-                   const uint32_t* __restrict__ giveup, int part)
+                   const uint32_t* __restrict__ giveup, int part, int list_cap,
+                   int* __restrict__ tile_feedback)
 {
    __shared__ AccelLds L;
    float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
@@ -644,12 +662,14 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int tid = threadIdx.x;
    const int wg = xcd_workgroup(blockIdx.x, gridDim.x);
    const int p0 = begin + wg * TILE_THREADS;
+   // (the density pass has finished: what it counted goes to the host's pinned copy)
+   if (blockIdx.x == 0 && tid == 0) tile_feedback[TSTAT_NO_LIST] = tile_stats[TSTAT_NO_LIST];
    // nothing of its own to do for workgroups past the range or made of ghosts only - nor, when
    // the pass is launched in two parts (early exchange), for those of the other part
    const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&
                     accel_part_has(part, p0, meta);
    // 1: tile did not fit the density pass (on the give-up list), 2: some particle of the
-   // workgroup has no list (more neighbours than NLIST_CAP)
+   // workgroup has no list (more neighbours than list_cap)
    const uint32_t gave_up = own ? nlist_overflow[wg] : 1u;
    // the first workgroups of the launch start with the workgroups whose tile does not fit
    // (give-up list), untiled, so that their long latency overlaps the rest of the launch
@@ -664,9 +684,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    {
       const int pp = p0 + tid;
       // (the true count of a particle without a list can exceed the histogram: one bin for all)
-      if (pp < end && pp >= ob && pp < oe) my_cnt = min(ncount[pp], NLIST_CAP);
+      if (pp < end && pp >= ob && pp < oe) my_cnt = min(ncount[pp], list_cap) >> hist_shift(list_cap);
    }
-   if (tid <= NLIST_CAP) L.hist[tid] = 0;   // (the descriptor load's barrier covers this too)
+   if (tid < HIST_BINS) L.hist[tid] = 0;   // (the descriptor load's barrier covers this too)
    tile_desc_load(desc, wg, L.desc);
    const int total = L.desc.total;
    if (total > tile_cap) return;  // does not fit this pass's wider entries: on the give-up list
@@ -699,12 +719,12 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int slot = atomicAdd(&L.hist[my_cnt], 1);
    __syncthreads();
    if (tid < SPH_WAVE) {
-      // exclusive scan of hist[0..NLIST_CAP] by one wave (HIST_PER_LANE consecutive bins per lane)
+      // exclusive scan of the histogram by one wave (HIST_PER_LANE consecutive bins per lane)
       int bin[HIST_PER_LANE];
       int sum = 0;
 #pragma unroll
       for (int u = 0; u < HIST_PER_LANE; u++) {
-         bin[u] = (HIST_PER_LANE * tid + u <= NLIST_CAP) ? L.hist[HIST_PER_LANE * tid + u] : 0;
+         bin[u] = L.hist[HIST_PER_LANE * tid + u];
          sum += bin[u];
       }
       int inc = sum;
@@ -716,7 +736,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       int ex = inc - sum;
 #pragma unroll
       for (int u = 0; u < HIST_PER_LANE; u++) {
-         if (HIST_PER_LANE * tid + u <= NLIST_CAP) L.hist[HIST_PER_LANE * tid + u] = ex;
+         L.hist[HIST_PER_LANE * tid + u] = ex;
          ex += bin[u];
       }
    }
@@ -766,7 +786,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    accel_begin(k, s, pi, vi, rho_i);
    // every listed pair passed the exact d2 < h2 test: the division's range checks are uniform
    const bool in_range = accel_operands_in_range(k);
-   const uint32_t* my_list = nlist + (size_t)wg * (NLIST_WORDS * TILE_THREADS) + col;
+   const uint32_t* my_list = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS) + col;
    // a particle without a list (marker in its first word; only in workgroups flagged 2): its lane
    // skips the list loop and walks its candidate ranges in the tile afterwards
    bool no_list = false;

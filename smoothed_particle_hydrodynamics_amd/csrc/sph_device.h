@@ -75,7 +75,8 @@ enum {
    TSTAT_MAX = 13,            // largest tile
    TSTAT_GIVEUP_DENSITY = 14, // entries of the give-up lists of the current step
    TSTAT_GIVEUP_ACCEL = 15,
-   TSTAT_COUNT = 16
+   TSTAT_NO_LIST = 16,        // particles with more neighbours than their list holds (density pass)
+   TSTAT_COUNT = 17
 };
 struct TileCaps {
    int cand[TILE_CANDS];    // ascending candidate capacities (the occupancy levels of both kernels)
@@ -174,6 +175,9 @@ struct sph_hip_context {
    uint32_t* giveup_density = nullptr; // workgroups whose tile exceeds the density capacity
    uint32_t* giveup_accel = nullptr;   // ... or the acceleration capacity
    int tile_cap_forced = 0;        // SPH_HIP_TILE_CAP: fixed capacity for both kernels (tests)
+   int list_cap = 0;               // neighbours per particle the lists hold (even)
+   int list_cap_max = 0;           // how far the host may enlarge them (SPH_HIP_LIST_CAP pins both)
+   size_t list_blocks = 0;         // workgroup blocks the list allocation covers
    int density_levels[TILE_CANDS] = {0}, n_density_levels = 0;
    int accel_levels[TILE_CANDS] = {0}, n_accel_levels = 0;
    int density_per_cu[TILE_CANDS] = {0}, accel_per_cu[TILE_CANDS] = {0};  // workgroups per CU at each level

@@ -243,9 +243,39 @@ int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, con
 
 // Capacities for the step about to be launched (before its k_tile_desc, which lists the
 // workgroups that will not fit them).
+// The density pass of an earlier step reported particles with more neighbours than their lists
+// hold (those lanes walk their candidates one by one in both passes, an order of magnitude
+// slower per particle): double the lists' capacity for the steps from here on.  The device has
+// to be idle for the exchange of the allocation - once or twice in a run that compresses.
+// Never changes results, only which route a particle takes.
+void grow_lists(sph_hip_context* ctx)
+{
+   const int want = ctx->list_cap * 2 + 2 > ctx->list_cap_max ? ctx->list_cap_max : ctx->list_cap * 2 + 2;
+   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;   // (reported by the step itself)
+   uint32_t* bigger = nullptr;
+   const size_t words = ctx->list_blocks * list_rows(want) * TILE_THREADS;
+   if (dev_alloc(&bigger, words) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->list_cap_max = ctx->list_cap;   // no memory for it: stay, and do not ask again
+      return;
+   }
+   (void)hipFree(ctx->nlist);
+   (void)hipMemsetAsync(bigger, 0, words * sizeof(uint32_t), ctx->stream);
+   ctx->nlist = bigger;
+   ctx->list_cap = want;
+   ((volatile int*)ctx->tile_feedback)[TSTAT_NO_LIST] = 0;
+   static const bool debug = getenv("SPH_HIP_DEBUG") != nullptr;
+   if (debug) fprintf(stderr, "sph_hip: neighbour lists enlarged to %d entries\n", want);
+}
+
 void pick_tile_caps(sph_hip_context* ctx)
 {
    TileCaps& caps = ctx->caps;
+   if (ctx->list_cap < ctx->list_cap_max) {
+      const int without = ((volatile int*)ctx->tile_feedback)[TSTAT_NO_LIST];
+      const int blocks = ((volatile int*)ctx->tile_feedback)[TSTAT_BLOCKS];
+      if (without > 64 && without > blocks * (TILE_THREADS / 256)) grow_lists(ctx);   // > 0.4 %
+   }
    if (caps.n_cand == 0) {
       allow_large_tiles();
       ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true, false>, DENSITY_TILE_BYTES,
@@ -426,7 +456,7 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
                       ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
                       ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
-                      ctx->giveup_density, ctx->tile_feedback)
+                      ctx->giveup_density, ctx->tile_feedback, ctx->list_cap)
 #define SPH_GO(U, M)                                                                             \
    do {                                                                                          \
       if (ctx->caps.wide) SPH_GO3(U, M, true);                                                   \
@@ -455,7 +485,7 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
                       st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
                       ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
-                      ctx->giveup_accel, part)
+                      ctx->giveup_accel, part, ctx->list_cap, ctx->tile_feedback)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -877,7 +907,14 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
       CREATE_TRY(dev_alloc(&ctx->velB, cap));
       CREATE_TRY(dev_alloc(&ctx->auxc, cap));
       CREATE_TRY(dev_alloc(&ctx->tile_desc, (size_t)div_up(capacity, TILE_THREADS) + 1));
-      const size_t nlist_words = ((size_t)div_up(capacity, TILE_THREADS) + 1) * NLIST_WORDS * TILE_THREADS;
+      ctx->list_cap = NLIST_CAP;
+      ctx->list_cap_max = NLIST_CAP_MAX;
+      if (const char* v = getenv("SPH_HIP_LIST_CAP")) {
+         const int c = atoi(v) / 2 * 2;
+         if (c > 0) ctx->list_cap = ctx->list_cap_max = c < 2 ? 2 : (c > NLIST_CAP_MAX ? NLIST_CAP_MAX : c);
+      }
+      ctx->list_blocks = (size_t)div_up(capacity, TILE_THREADS) + 1;
+      const size_t nlist_words = ctx->list_blocks * list_rows(ctx->list_cap) * TILE_THREADS;
       CREATE_TRY(dev_alloc(&ctx->nlist, nlist_words));
       // touched once here, so that the first step does not pay for mapping the pages
       CREATE_TRY(hipMemsetAsync(ctx->nlist, 0, nlist_words * sizeof(uint32_t), ctx->stream));
@@ -1769,11 +1806,11 @@ int sph_hip_get_tile_stats(sph_hip_context* ctx, int32_t out[20])
    if (rc) return rc;
    if (!out || !ctx->tile_feedback) return SPH_HIP_ERR_INVALID;
    SPH_TRY(hipStreamSynchronize(ctx->stream));
-   for (int i = 0; i < TSTAT_COUNT; i++) out[i] = ctx->tile_feedback[i];
+   for (int i = 0; i < 16; i++) out[i] = ctx->tile_feedback[i];
    out[16] = ctx->caps.cap_density;
    out[17] = ctx->caps.cap_accel;
    out[18] = ctx->caps.wide;
-   out[19] = 0;
+   out[19] = ctx->list_cap;
    return SPH_HIP_OK;
 }
 

@@ -285,7 +285,8 @@ class SPH:
         v = list(out)
         return {"over_level": v[0:12], "workgroups": v[12], "largest_tile": v[13],
                 "untiled_density": v[14], "untiled_acceleration": v[15],
-                "capacity_density": v[16], "capacity_acceleration": v[17], "wide_entries": v[18]}
+                "capacity_density": v[16], "capacity_acceleration": v[17], "wide_entries": v[18],
+                "list_capacity": v[19]}
 
     def phaseTotals(self):
         """(sum of the six phase times in ms over the step() calls since resetTimings(), steps)"""

@@ -185,6 +185,49 @@ def test_full_any_tile_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
     run_case(oracle, p, pos, vel, mass, steps=2)
 
 
+@pytest.mark.parametrize("cap", ["30", "254", "510", "1022"])
+def test_full_any_list_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
+    """The neighbour lists' capacity is a launch argument (SPH_HIP_LIST_CAP pins it).  With 30
+    entries half the particles of this scene go without a list and walk their candidates in both
+    passes; 510 and 1022 use the coarser bins of the acceleration pass's lane deal.  Same bits."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    monkeypatch.setenv("SPH_HIP_LIST_CAP", cap)
+    p, pos, vel, mass = scenes.dam_break(60000)
+    run_case(oracle, p, pos, vel, mass, steps=2)
+    with S.SPH(mass.size, p) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.step()
+        assert sph.tileStats()["list_capacity"] == int(cap)
+        if cap == "30":
+            assert (sph.getParticles().mNeighborCount > 30).sum() > mass.size // 4
+
+
+def test_full_lists_grow_when_the_scene_compresses(oracle, hiplib, monkeypatch):
+    """A column 11x denser than the benchmark's (what a breaking dam compresses to): most
+    particles have more than 254 neighbours.  The density pass reports them, the host doubles the
+    lists for the following steps (254 -> 510), and every step - before and after the change -
+    equals the oracle."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    monkeypatch.delenv("SPH_HIP_LIST_CAP", raising=False)
+    p, _, _, _ = scenes.dam_break(40000)
+    _, pos, vel, mass = scenes.dam_break(40000, fill=(0.04, 0.4, 0.42))    # 11x denser, same h
+    op = to_oracle_params(p)
+    seen = []
+    with S.SPH(mass.size, p, mode=S.MODE_FULL) as sph:
+        sph.setParticles(pos, vel, mass)
+        oq, ov = pos.copy(), vel.copy()
+        for s in range(4):
+            sph.step()
+            ref = oracle.step(op, oq, ov, mass, mode="full")
+            check_state(sph.getParticles(), ref)
+            seen.append(sph.tileStats()["list_capacity"])
+        nb = sph.getParticles().mNeighborCount
+    assert (nb > 254).mean() > 0.3 and nb.max() <= 1022, (nb.mean(), nb.max())
+    assert seen[0] == 254 and seen[-1] in (510, 1022), seen
+
+
 def test_full_capacity_follows_the_scene(oracle, hiplib):
     """Same context, two uploads of very different density: the capacity chosen from the first
     scene's statistics must not leak wrong results into the second (it is only a hint)."""

@@ -15,4 +15,4 @@ for blk in range(16):
     part=sph.getParticles()
     c=part.mNeighborCount
     ts=sph.tileStats()
-    print("steps %4d: %.3f ms/step [build %.2f dens %.2f acc %.2f]  nb mean %.1f max %d >254: %d | wg %d largest tile %d caps %d/%d untiled %d/%d" % ((blk+1)*51, dt*1e3, t[0],t[2],t[4], c.mean(), c.max(), (c>254).sum(), ts["workgroups"], ts["largest_tile"], ts["capacity_density"], ts["capacity_acceleration"], ts["untiled_density"], ts["untiled_acceleration"]) + (" wide" if ts["wide_entries"] else ""), flush=True)
+    print("steps %4d: %.3f ms/step [build %.2f dens %.2f acc %.2f]  nb mean %.1f max %d >254: %d >510: %d p50 %d p90 %d p99 %d | wg %d largest tile %d caps %d/%d untiled %d/%d" % ((blk+1)*51, dt*1e3, t[0],t[2],t[4], c.mean(), c.max(), (c>254).sum(), (c>510).sum(), int(np.percentile(c,50)), int(np.percentile(c,90)), int(np.percentile(c,99)), ts["workgroups"], ts["largest_tile"], ts["capacity_density"], ts["capacity_acceleration"], ts["untiled_density"], ts["untiled_acceleration"]) + (" wide" if ts["wide_entries"] else ""), flush=True)
