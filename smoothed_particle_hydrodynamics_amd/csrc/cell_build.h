@@ -172,7 +172,13 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
    uint32_t v[SCAN_ITEMS];
    uint32_t s = 0;
-   if (base + SCAN_ITEMS <= ncells) {
+   // A tile without particles (most of them when the fluid fills a corner of the box): its counts
+   // are known - zero - and stay as they are; only cell_start = the carry is written.
+   const bool empty_tile = part[blockIdx.x] == 0u;
+   if (empty_tile) {
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; k++) v[k] = 0u;
+   } else if (base + SCAN_ITEMS <= ncells) {
       const uint4* p = reinterpret_cast<const uint4*>(count + base);
 #pragma unroll
       for (int k = 0; k < SCAN_ITEMS / 4; k++) {
@@ -205,13 +211,13 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
          q.z = run; run += v[4 * k + 2];
          q.w = run; run += v[4 * k + 3];
          o[k] = q;
-         z[k] = make_uint4(0, 0, 0, 0);
+         if (!empty_tile) z[k] = make_uint4(0, 0, 0, 0);
       }
    } else {
       for (int k = 0; k < SCAN_ITEMS; k++) {
          if (base + k < ncells) {
             cell_start[base + k] = run;
-            count[base + k] = 0;
+            if (!empty_tile) count[base + k] = 0;
             run += v[k];
          }
       }
