@@ -240,7 +240,9 @@ k_rank_gather_tile_desc(int desc_blocks, int ntiles, const uint32_t* __restrict_
                 caps, stats, giveup_density, giveup_accel);
       return;
    }
-   rank_gather((blockIdx.x - desc_blocks) * blockDim.x + threadIdx.x, perm, key, cell_start, meta,
+   __shared__ uint32_t lds_id[256];
+   rank_gather((blockIdx.x - desc_blocks) * blockDim.x + threadIdx.x,
+               (blockIdx.x - desc_blocks) * blockDim.x, lds_id, perm, key, cell_start, meta,
                g.ncells, posm_in, velp_in, posm_out, velp_out, remap);
 }
 
