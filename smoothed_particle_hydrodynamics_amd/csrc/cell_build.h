@@ -211,13 +211,15 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
          q.z = run; run += v[4 * k + 2];
          q.w = run; run += v[4 * k + 3];
          o[k] = q;
-         if (!empty_tile) z[k] = make_uint4(0, 0, 0, 0);
+         // (counts that are zero already - nine cells in ten of a column in a corner of the box -
+         // are not written again)
+         if ((v[4 * k + 0] | v[4 * k + 1] | v[4 * k + 2] | v[4 * k + 3]) != 0u) z[k] = make_uint4(0, 0, 0, 0);
       }
    } else {
       for (int k = 0; k < SCAN_ITEMS; k++) {
          if (base + k < ncells) {
             cell_start[base + k] = run;
-            if (!empty_tile) count[base + k] = 0;
+            if (v[k] != 0u) count[base + k] = 0;
             run += v[k];
          }
       }
