@@ -794,6 +794,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    bool no_list = false;
    if (gave_up == 2u && cnt > 0) no_list = my_list[0] == NLIST_NO_LIST;
    if (no_list) cnt = 0;
+#if defined(SPH_ABLATE) && SPH_ABLATE == 21
+   cnt = 0;   // timing only: prologue and epilogue
+#endif
    // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
    // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
    // so neither of a neighbour's two dependent memory round trips is waited for in isolation.
@@ -832,8 +835,12 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             float d = sqrt_rn(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
+#if defined(SPH_ABLATE) && SPH_ABLATE == 22
+            s.pgx += d + vj[u].x + pj.w;   // timing only: no pair arithmetic
+#else
             accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
                                    pj.w, in_range);
+#endif
          }
       }
    }
