@@ -103,12 +103,7 @@ typedef struct sph_hip_context sph_hip_context;
 int sph_hip_params_default(sph_hip_params* out, float h, int cells_x, int cells_y, int cells_z);
 
 /* Replaces the allocations in SPH::SPH() (reference src/sph.cpp:100-113): device storage for
- * up to `capacity` particles on HIP device `device`.  FULL mode takes about 0.8 KB of device
- * memory per particle of capacity plus 8 bytes per cell of the search grid; its neighbour lists
- * (0.5 KB per particle of that) are reallocated at 1 KB and then 2 KB per particle by the step
- * that follows one in which more than 0.4 % of the particles had more neighbours than their list
- * holds (sph_hip_get_tile_stats out[19]; if the device has no room for that, the lists stay as
- * they are and those particles keep being computed without a list: slower, same results). */
+ * up to `capacity` particles on HIP device `device`. */
 int sph_hip_create(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
                    int device);
 void sph_hip_destroy(sph_hip_context* ctx);
