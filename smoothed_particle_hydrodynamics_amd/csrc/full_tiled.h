@@ -61,15 +61,7 @@ __host__ __device__ __forceinline__ constexpr int list_rows(int list_cap) { retu
 // first list word of a particle that has no list (more neighbours than list_cap): no valid
 // entry has segment id 15
 #define NLIST_NO_LIST 0xffffffffu
-// The acceleration pass deals its lanes by neighbour count through a histogram of HIST_BINS
-// bins: bin = min(count, list_cap) >> hist_shift(list_cap).
-#define HIST_BINS 256
-#define HIST_PER_LANE (HIST_BINS / SPH_WAVE)
-__host__ __device__ __forceinline__ constexpr int hist_shift(int list_cap)
-{
-   return list_cap < HIST_BINS ? 0 : (list_cap < 2 * HIST_BINS ? 1 : 2);
-}
-static_assert((NLIST_CAP_MAX >> hist_shift(NLIST_CAP_MAX)) < HIST_BINS && NLIST_CAP <= NLIST_CAP_MAX, "histogram bins");
+static_assert(NLIST_CAP <= NLIST_CAP_MAX, "initial list capacity");
 // list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
 #ifndef DENSITY_UNROLL
 #define DENSITY_UNROLL 6
@@ -625,10 +617,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // single neighbours up, so one ds_read_b128 per neighbour beats four scattered ds_read_b32.
 struct AccelLds {
    TileDesc desc;
-   int hist[HIST_BINS];            // neighbour-count histogram / its exclusive scan
-   uint16_t perm[TILE_THREADS];    // lane -> list column, ascending neighbour count
 };
-static_assert(HIST_BINS <= TILE_THREADS, "the histogram is cleared by one thread per bin");
 
 // The acceleration pass can be launched in two parts (early exchange): part 1 = the workgroups
 // that hold a particle of the owned planes next to a neighbouring slab (sorted ranges
@@ -682,13 +671,6 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          accel_untiled<UNIT_SCALE>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
    }
    if (gave_up == 1u) return;
-   int my_cnt = 0;  // requested before the tile: the lane permutation below needs it
-   {
-      const int pp = p0 + tid;
-      // (the true count of a particle without a list can exceed the histogram: one bin for all)
-      if (pp < end && pp >= ob && pp < oe) my_cnt = min(ncount[pp], list_cap) >> hist_shift(list_cap);
-   }
-   if (tid < HIST_BINS) L.hist[tid] = 0;   // (the descriptor load's barrier covers this too)
    tile_desc_load(desc, wg, L.desc);
    const int total = L.desc.total;
    if (total > tile_cap) return;  // does not fit this pass's wider entries: on the give-up list
@@ -699,8 +681,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       D[kk] = L.desc.D[kk];
    }
    // Prologue order: the first batch of tile loads is issued, then - while it is in flight - the
-   // lanes are dealt their particles, whose own loads and first list words go out next; only then
-   // are the tile's entries stored to LDS.  Unconditional loads, index clamped into the tile (see
+   // lanes' own loads go out; only then are the tile's entries stored to LDS.  Unconditional loads, index clamped into the tile (see
    // tile_load).
    float4 buf[TILE_BATCH];
    float cbuf[TILE_BATCH];
@@ -714,39 +695,12 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       cbuf[r] = auxc[idx - d];
    }
 
-   // Lane <-> particle assignment: the loop below runs to the largest neighbour count in the
-   // wave, so lanes are handed particles in order of their count (counting sort through LDS):
-   // every wave then works on particles with nearly equal counts.  Each lane's sum is
-   // independent, so the assignment does not change any result.
-   const int slot = atomicAdd(&L.hist[my_cnt], 1);
-   __syncthreads();
-   if (tid < SPH_WAVE) {
-      // exclusive scan of the histogram by one wave (HIST_PER_LANE consecutive bins per lane)
-      int bin[HIST_PER_LANE];
-      int sum = 0;
-#pragma unroll
-      for (int u = 0; u < HIST_PER_LANE; u++) {
-         bin[u] = L.hist[HIST_PER_LANE * tid + u];
-         sum += bin[u];
-      }
-      int inc = sum;
-#pragma unroll
-      for (int dd = 1; dd < SPH_WAVE; dd <<= 1) {
-         const int o = __shfl_up(inc, dd);
-         if (tid >= dd) inc += o;
-      }
-      int ex = inc - sum;
-#pragma unroll
-      for (int u = 0; u < HIST_PER_LANE; u++) {
-         L.hist[HIST_PER_LANE * tid + u] = ex;
-         ex += bin[u];
-      }
-   }
-   __syncthreads();
-   L.perm[L.hist[my_cnt] + slot] = (uint16_t)tid;
-   __syncthreads();
-   const int col = L.perm[tid];  // the particle (column of the list block) this lane works on
-
+   // Lanes keep their own particle.  (Rounds 1-2 dealt the workgroup's particles to the lanes in
+   // order of neighbour count - counting sort through LDS, three barriers - so that a wave's loop
+   // length was uniform; with the pass as it is now, not doing it measures 10 us faster at 4M and
+   // 110 us at 16M: consecutive particles share most of their neighbours, dealt lanes gather from
+   // all over the tile, and the 1.5 KB of LDS are better spent on tile capacity.)
+   const int col = tid;  // the particle (column of the list block) this lane works on
    const int p = p0 + col;
    const bool live = p < end && p >= ob && p < oe;
    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -189,7 +189,7 @@ def test_full_any_tile_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
 def test_full_any_list_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
     """The neighbour lists' capacity is a launch argument (SPH_HIP_LIST_CAP pins it).  With 30
     entries half the particles of this scene go without a list and walk their candidates in both
-    passes; 510 and 1022 use the coarser bins of the acceleration pass's lane deal.  Same bits."""
+    passes; 510 and 1022 are what a compressing scene grows them to.  Same bits."""
     import smoothed_particle_hydrodynamics_amd as S
     from smoothed_particle_hydrodynamics_amd import scenes
     monkeypatch.setenv("SPH_HIP_LIST_CAP", cap)
