@@ -62,9 +62,10 @@ __host__ __device__ __forceinline__ constexpr int list_rows(int list_cap) { retu
 // entry has segment id 15
 #define NLIST_NO_LIST 0xffffffffu
 static_assert(NLIST_CAP <= NLIST_CAP_MAX, "initial list capacity");
-// list entries fetched per trip of the SUM loops (measured best on MI355X: 6 / 8)
+// list entries fetched per trip of the SUM loops (measured best on MI355X: 8 / 8; the density
+// pass ran best with 6 until the end of round 2, now 8 or 10 are 5-10 us ahead of it at 4M)
 #ifndef DENSITY_UNROLL
-#define DENSITY_UNROLL 6
+#define DENSITY_UNROLL 8
 #endif
 #ifndef APPEND_POPS
 #define APPEND_POPS 4     // accepted candidates appended per trip of the append loop
