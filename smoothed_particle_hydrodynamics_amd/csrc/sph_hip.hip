@@ -142,21 +142,34 @@ int check_ctx(sph_hip_context* ctx)
 
 // ---- LDS tile capacity ---------------------------------------------------------------------
 // For every workgroups-per-CU count B a tiled kernel can reach, the largest tile (multiple of
-// 32 entries) that still lets B workgroups share a CU.  The runtime's occupancy calculator
-// knows the kernel's registers and static LDS; 2 KiB of slack per workgroup cover the
-// allocation granularity of the hardware, which it rounds more finely than the device does
-// (measured: a size it rated 3/CU ran at 2/CU).
+// 32 entries) that still lets B workgroups share a CU.  Registers and waves: the runtime's
+// occupancy calculator.  LDS: the MI355X hands a workgroup its LDS (static + dynamic) in units of
+// 1280 bytes out of 160 KiB per CU - measured with a sweep of pinned capacities (tools/cap_sweep.py:
+// the density pass drops from 6 to 5 workgroups per CU between 2176 and 2208 entries and from 5 to
+// 4 between 2624 and 2656, the acceleration pass from 4 to 3 between 2496 and 2528; the
+// calculator's own rounding is finer, and a size it rated 3/CU ran at 2/CU, which rounds 1-2 used
+// to cover with 2 KiB of slack per workgroup at the price of 130-190 entries per level).
+#define LDS_PER_CU (160 * 1024)
+#define LDS_GRANULE 1280
 template <class Kernel>
 int tile_levels(Kernel kernel, int bytes_per_entry, int* levels, int* per_cu)
 {
+   hipFuncAttributes attr;
+   size_t static_lds = 2048;   // (no answer: the old slack)
+   if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) == hipSuccess)
+      static_lds = attr.sharedSizeBytes;
+   else
+      (void)hipGetLastError();
    auto blocks_at = [&](int cap) {
       int nb = 0;
-      const size_t bytes = (size_t)(cap + TILE_PAD) * bytes_per_entry + 2048;
+      const size_t bytes = (size_t)(cap + TILE_PAD) * bytes_per_entry;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, TILE_THREADS, bytes) != hipSuccess) {
          (void)hipGetLastError();
          return 0;
       }
-      return nb;
+      const size_t granules = (static_lds + bytes + LDS_GRANULE - 1) / LDS_GRANULE;
+      const int by_lds = (int)(LDS_PER_CU / (granules * LDS_GRANULE));
+      return nb < by_lds ? nb : by_lds;
    };
    // a workgroup may take the whole LDS of a CU (160 KiB); the 14-bit tile index of wide list
    // entries stops a little earlier for 12-byte entries
