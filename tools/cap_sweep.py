@@ -3,7 +3,7 @@
 pass loses a workgroup per CU, i.e. the LDS allocation granularity of the device (DESIGN.md 3,
 csrc/sph_hip.hip tile_levels).  One process per capacity."""
 import sys, time, os, subprocess
-if len(sys.argv) > 1:
+if os.environ.get("CAP_SWEEP_CHILD"):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import smoothed_particle_hydrodynamics_amd as S
     from smoothed_particle_hydrodynamics_amd import scenes
@@ -16,6 +16,6 @@ if len(sys.argv) > 1:
     t,k=sph.phaseTotals()
     print("cap %s density %.1f accel %.1f us" % (os.environ.get("SPH_HIP_TILE_CAP"), t[2]/k*1e3, t[4]/k*1e3), flush=True)
 else:
-    for cap in range(2016, 2760, 32):
-        env=dict(os.environ, SPH_HIP_TILE_CAP=str(cap))
+    for cap in [int(a) for a in sys.argv[1:]] or range(2016, 2760, 32):
+        env=dict(os.environ, SPH_HIP_TILE_CAP=str(cap), CAP_SWEEP_CHILD="1")
         subprocess.run([sys.executable, __file__, "x"], env=env, timeout=200)
