@@ -507,6 +507,12 @@ def main():
                 "launch_pairs_timed": covered,
                 "note": "VALU-bound gather-sum: see DESIGN.md (Roofline); frac is against the "
                         "64 B/particle compulsory-traffic figure of SURVEY.md 8(d)",
+                "fused_work": None if world > 1 else (
+                    "on one GPU the acceleration launch of the pair also integrates every particle "
+                    "and hashes + counts it for the next cell build (no k_integrate launch: "
+                    "phases_ms.integrate is an event gap): 60 + 20 B/particle more of SURVEY.md "
+                    "8(d)'s algorithmic bytes done inside ms_per_launch_pair and NOT counted in "
+                    "achieved / frac"),
             },
         }
         if world > 1:

@@ -23,6 +23,7 @@
 // code of full_kernels.h inline — same results, slower, no extra launch.
 #pragma once
 
+#include "common_kernels.h"
 #include "full_kernels.h"
 
 // The tile lives in dynamic LDS: its capacity (candidate positions per workgroup) is a launch
@@ -634,6 +635,52 @@ __device__ __forceinline__ bool accel_part_has(int part, int p0, const int32_t* 
    return border == (part == 1);
 }
 
+// FusedStep: what k_integrate<., HASH = true> does for particle p (position x, acceleration a), by
+// the workgroup that computed a.  Called by all threads of the workgroup; wg_index = the
+// workgroup of 256 particles p belongs to (its slot in the energy partial sums).
+template <bool UNIT_SCALE>
+__device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairConsts& k,
+                                                const CellGrid& g, int p, bool live, float4 x,
+                                                float4 a, int wg_index)
+{
+   double ke = 0.0, pe = 0.0;
+   uint32_t c = 0xffffffffu;
+   if (live) {
+      float4 v = fs.velp_in[p];
+      integrate_particle<UNIT_SCALE>(k, x, v, a, ke, pe);
+      fs.posm_out[p] = x;
+      fs.velp_out[p] = v;
+      int cx, cy, cz;
+      c = cell_of(g, x.x, x.y, x.z, cx, cy, cz);
+      fs.key[p] = c;
+   }
+   count_cell_runs(c, live, p, fs.cell_count, fs.slot);
+   // block reduction, fixed order (the same as k_integrate's: same partial sums)
+   __shared__ double s_ke[TILE_THREADS / SPH_WAVE], s_pe[TILE_THREADS / SPH_WAVE];
+#pragma unroll
+   for (int d = SPH_WAVE / 2; d > 0; d >>= 1) {
+      ke += __shfl_down(ke, d);
+      pe += __shfl_down(pe, d);
+   }
+   const int lane = threadIdx.x & (SPH_WAVE - 1), w = threadIdx.x / SPH_WAVE;
+   if (lane == 0) {
+      s_ke[w] = ke;
+      s_pe[w] = pe;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int q = 0; q < TILE_THREADS / SPH_WAVE; q++) {
+         sa += s_ke[q];
+         sb += s_pe[q];
+      }
+      fs.epart[2 * wg_index + 0] = sa;
+      fs.epart[2 * wg_index + 1] = sb;
+   }
+   __syncthreads();
+}
+
 template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE>
 __global__ void __launch_bounds__(TILE_THREADS, ACCEL_BLOCKS)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
@@ -644,7 +691,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                    const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow,
                    int tile_cap, const int32_t* __restrict__ tile_stats,
                    const uint32_t* __restrict__ giveup, int part, int list_cap,
-                   int* __restrict__ tile_feedback)
+                   int* __restrict__ tile_feedback, FusedStep fs)
 {
    __shared__ AccelLds L;
    float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
@@ -668,8 +715,16 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    if ((int)blockIdx.x < tile_stats[TSTAT_GIVEUP_ACCEL]) {
       const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
       const int gp = g0 + tid;
-      if (gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta))
-         accel_untiled<UNIT_SCALE>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
+      const bool mine = gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta);
+      if (mine) accel_untiled<UNIT_SCALE>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
+      if (fs.on) {
+         float4 gx = make_float4(0.f, 0.f, 0.f, 0.f), ga = gx;
+         if (mine) {
+            gx = posm[gp];
+            ga = acc[gp];   // (written by this thread just above)
+         }
+         fused_integrate<UNIT_SCALE>(fs, k, g, gp, mine, gx, ga, (int)giveup[blockIdx.x]);
+      }
    }
    if (gave_up == 1u) return;
    tile_desc_load(desc, wg, L.desc);
@@ -825,5 +880,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          }
       }
    }
-   if (live) acc[p] = accel_end<UNIT_SCALE>(k, s);
+   const float4 a_i = accel_end<UNIT_SCALE>(k, s);
+   if (live) acc[p] = a_i;
+   if (fs.on) fused_integrate<UNIT_SCALE>(fs, k, g, p, live, pi, a_i, wg);
 }

@@ -78,6 +78,21 @@ enum {
    TSTAT_NO_LIST = 16,        // particles with more neighbours than their list holds (density pass)
    TSTAT_COUNT = 17
 };
+// The rest of the step, done by the acceleration pass itself (a context that holds the whole
+// grid and exchanges with nobody): every particle is integrated where its acceleration was just
+// computed - into the state buffers the cell build left free, the neighbours still read the old
+// ones - and hashed and counted for the next cell build; no k_integrate launch, no second trip of
+// positions, velocities and accelerations through HBM.
+struct FusedStep {
+   int on;
+   const float4* velp_in;   // velocity + id of the state the sums read
+   float4* posm_out;        // the other pair of state buffers
+   float4* velp_out;
+   double* epart;           // energy partial sums, one pair per workgroup (as k_integrate)
+   uint32_t* key;           // next build: cell id, slot inside the cell, the cells' counts
+   uint32_t* slot;
+   uint32_t* cell_count;
+};
 struct TileCaps {
    int cand[TILE_CANDS];    // ascending candidate capacities (the occupancy levels of both kernels)
    int n_cand;

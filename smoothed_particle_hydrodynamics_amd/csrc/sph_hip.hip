@@ -484,8 +484,20 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
 }
 
 void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part,
-                        hipStream_t st)
+                        hipStream_t st, bool fused = false)
 {
+   FusedStep fs;
+   memset(&fs, 0, sizeof(fs));
+   if (fused) {
+      fs.on = 1;
+      fs.velp_in = ctx->velp[ctx->cur];
+      fs.posm_out = ctx->posm[ctx->cur ^ 1];
+      fs.velp_out = ctx->velp[ctx->cur ^ 1];
+      fs.epart = ctx->epart + 2;
+      fs.key = ctx->key;
+      fs.slot = ctx->slot;
+      fs.cell_count = ctx->cell_count;
+   }
    const int cap = ctx->caps.cap_accel;
    const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
 #define SPH_GO(U, M)                                                                             \
@@ -498,7 +510,7 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
                       st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
                       ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
                       ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
-                      ctx->giveup_accel, part, ctx->list_cap, ctx->tile_feedback)
+                      ctx->giveup_accel, part, ctx->list_cap, ctx->tile_feedback, fs)
    if (unit && ctx->uniform_mass) SPH_GO(true, true);
    else if (unit) SPH_GO(true, false);
    else if (ctx->uniform_mass) SPH_GO(false, true);
@@ -536,7 +548,7 @@ int launch_density(sph_hip_context* ctx)
 
 // part: 0 = all workgroups; 1 / 2 = those with / without particles of the owned planes next to
 // a neighbouring slab (early exchange; tiled FULL mode only)
-int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = nullptr)
+int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = nullptr, bool fused = false)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
@@ -550,7 +562,7 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         launch_accel_lists(ctx, unit, div_up(n, TILE_THREADS), k, part, part ? part_stream : ctx->stream);
+         launch_accel_lists(ctx, unit, div_up(n, TILE_THREADS), k, part, part ? part_stream : ctx->stream, fused);
       } else if (unit) {
          hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
                             ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
@@ -652,13 +664,18 @@ int step_impl(sph_hip_context* ctx, bool timed)
    if (phases && phase_event(ctx, 2) == 2) SPH_TRY(hipEventRecord(ev[2], st));
    if ((rc = launch_density(ctx))) return rc;
    if (phases) SPH_TRY(hipEventRecord(ev[3], st));
-   if ((rc = launch_accel(ctx))) return rc;
-   if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
    // a context that holds the whole grid and has never exchanged anything: the integrate also
-   // hashes and counts for the next cell build
+   // hashes and counts for the next cell build - and the tiled acceleration pass does both itself
    const bool hash_too = ctx->mode == SPH_HIP_MODE_FULL && !ctx->had_exchange && ctx->plane_lo == 0 &&
                          ctx->plane_hi == ctx->grid.nz_global && !getenv_flag("SPH_HIP_NO_PREHASH");
-   if ((rc = launch_integrate(ctx, hash_too))) return rc;
+   const bool fused = hash_too && ctx->use_tiled && ctx->n > 0 && !getenv_flag("SPH_HIP_NO_FUSED_INTEGRATE");
+   if ((rc = launch_accel(ctx, 0, nullptr, fused))) return rc;
+   if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
+   if (fused) {
+      ctx->cur ^= 1;                                    // the new state is in the other buffers
+      ctx->energy_blocks = div_up(ctx->n, TILE_THREADS);
+      ctx->prehashed = 1;
+   } else if ((rc = launch_integrate(ctx, hash_too))) return rc;
    if (phases) SPH_TRY(hipEventRecord(ev[6], st));
    if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;
    return SPH_HIP_OK;

@@ -342,6 +342,41 @@ def test_full_long_run_adaptive_capacity_equals_fixed(hiplib, monkeypatch):
         assert np.array_equal(a, b)
 
 
+def test_full_fused_integrate_equals_the_separate_kernel(hiplib, monkeypatch):
+    """A context that holds the whole grid lets the acceleration pass integrate and hash every
+    particle itself (no k_integrate launch, new state written to the other pair of buffers);
+    SPH_HIP_NO_FUSED_INTEGRATE=1 keeps the separate kernel.  Same state, same sums and the same
+    energy totals, bit for bit, with gravity and walls switched on and a dense region that sends
+    workgroups down the untiled route."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(60000)
+    _, dense, _, _ = scenes.dam_break(60000, fill=(0.03, 0.3, 0.4))
+    pos = pos.copy()
+    pos[:3 * 20000] = dense[:3 * 20000]                 # 20 000 particles 28x denser: tiles overflow
+    p.apply_gravity = 1
+    p.apply_walls = 1
+    p.gravity[0], p.gravity[1], p.gravity[2] = 0.0, -9.81, 0.0
+    out = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("SPH_HIP_NO_FUSED_INTEGRATE", raising=False)
+        else:
+            monkeypatch.setenv("SPH_HIP_NO_FUSED_INTEGRATE", "1")
+        monkeypatch.setenv("SPH_HIP_TILE_CAP", "1504")     # a mix of tiled and untiled workgroups
+        with S.SPH(mass.size, p) as sph:
+            sph.setParticles(pos, vel, mass)
+            sph.run(5)
+            sph.step()
+            part = sph.getParticles()
+            ke, pe = sph.energy()
+            out.append([getattr(part, nm).copy() for nm in
+                        ("mPosition", "mVelocity", "mDensity", "mAcceleration", "mNeighborCount")] +
+                       [np.array([ke, pe])])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
 def test_full_step_then_phase_calls_and_uploads(oracle, hiplib):
     """sph_hip_step of a whole-grid context leaves the next build's cell hash done (inside the
     integrate kernel).  Everything that changes the state behind that - a stand-alone integrate,
