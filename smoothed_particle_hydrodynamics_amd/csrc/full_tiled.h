@@ -391,7 +391,11 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          density_untiled<UNIT_SCALE>(gp, posm, cell_start, velp, g, k, rho_out, velB_out, auxc_out,
                                      ncount);
    }
-   const int wg = xcd_workgroup(blockIdx.x, gridDim.x);
+   // (the mapping spreads the workgroups that exist over the XCDs: a slab context launches one
+   // workgroup per 256 particles of its CAPACITY, and dealing eighths of that grid left the XCDs
+   // of the empty tail idle - 3 of 8 with the usual 1.5x head room)
+   const int wgs = tile_stats[TSTAT_BLOCKS];
+   const int wg = (int)blockIdx.x < wgs ? xcd_workgroup(blockIdx.x, wgs) : (int)blockIdx.x;
    const int p0 = begin + wg * TILE_THREADS;
    if (p0 >= end) return;
    const int p = p0 + tid;
@@ -635,6 +639,33 @@ __device__ __forceinline__ bool accel_part_has(int part, int p0, const int32_t* 
    return border == (part == 1);
 }
 
+// Which workgroup hardware workgroup `block` of a launch of part `part` computes, or -1.  The
+// workgroups of a part are index ranges - border = the two ends of the owned range, interior = what
+// lies between - and each part spreads ITS workgroups over the XCDs (xcd_workgroup over the part's
+// count): a border launch that took its workgroups where the whole grid's mapping puts them ran
+// on two of the eight XCDs, the ones holding the ends of the sorted range.
+__device__ __forceinline__ int accel_part_workgroup(int part, int block, int wgs, int begin,
+                                                    const int32_t* __restrict__ meta)
+{
+   if (part == 0) return block < wgs ? xcd_workgroup(block, wgs) : -1;
+   const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+   const int lo_end = min(meta[META_BND_LO_END], oe);
+   const int hi_begin = min(max(meta[META_BND_HI_BEGIN], lo_end), oe);
+   // workgroup w holds sorted positions [begin + 256 w, + 256); see accel_part_has
+   const int first = min(max((ob - begin) / TILE_THREADS, 0), wgs);                        // first with owned particles
+   const int last = min(max((oe - begin + TILE_THREADS - 1) / TILE_THREADS, first), wgs);   // one past the last
+   const int b1 = lo_end > ob ? min(max((lo_end - begin + TILE_THREADS - 1) / TILE_THREADS, first), last) : first;
+   const int a2 = hi_begin < oe ? min(max((hi_begin - begin) / TILE_THREADS, b1), last) : last;
+   if (part == 1) {
+      const int n1 = b1 - first, count = n1 + (last - a2);
+      if (block >= count) return -1;
+      const int j = xcd_workgroup(block, count);
+      return j < n1 ? first + j : a2 + (j - n1);
+   }
+   const int count = a2 - b1;
+   return block < count ? b1 + xcd_workgroup(block, count) : -1;
+}
+
 // FusedStep: what k_integrate<., HASH = true> does for particle p (position x, acceleration a), by
 // the workgroup that computed a.  Called by all threads of the workgroup; wg_index = the
 // workgroup of 256 particles p belongs to (its slot in the energy partial sums).
@@ -699,13 +730,17 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
    const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
    const int tid = threadIdx.x;
-   const int wg = xcd_workgroup(blockIdx.x, gridDim.x);
+   // (the workgroups that exist - a slab context launches one per 256 particles of its CAPACITY -
+   // and, of those, the ones of this launch's part, spread over the XCDs)
+   const int wgs = tile_stats[TSTAT_BLOCKS];
+   const int mapped = accel_part_workgroup(part, blockIdx.x, wgs, begin, meta);
+   const int wg = mapped < 0 ? 0 : mapped;
    const int p0 = begin + wg * TILE_THREADS;
    // (the density pass has finished: what it counted goes to the host's pinned copy)
    if (blockIdx.x == 0 && tid == 0) tile_feedback[TSTAT_NO_LIST] = tile_stats[TSTAT_NO_LIST];
    // nothing of its own to do for workgroups past the range or made of ghosts only - nor, when
    // the pass is launched in two parts (early exchange), for those of the other part
-   const bool own = !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&
+   const bool own = mapped >= 0 && !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&
                     accel_part_has(part, p0, meta);
    // 1: tile did not fit the density pass (on the give-up list), 2: some particle of the
    // workgroup has no list (more neighbours than list_cap)

@@ -244,6 +244,16 @@ class HipSlab:
         return dict(ids=out["ids"][:n], pos=out["pos"][:3 * n], vel=out["vel"][:3 * n],
                     rho=out["rho"][:n], acc=out["acc"][:3 * n], ncount=out["ncount"][:n])
 
+    def tile_stats(self):
+        """dict of the last step's LDS-tile statistics (sph_hip_get_tile_stats), as SPH.tileStats()."""
+        out = (C.c_int32 * 20)()
+        self._check(self._lib.sph_hip_get_tile_stats(self._ctx, C.byref(out)), "sph_hip_get_tile_stats")
+        v = list(out)
+        return {"over_level": v[0:12], "workgroups": v[12], "largest_tile": v[13],
+                "untiled_density": v[14], "untiled_acceleration": v[15],
+                "capacity_density": v[16], "capacity_acceleration": v[17], "wide_entries": v[18],
+                "list_capacity": v[19]}
+
     def phase_totals(self):
         ms = (C.c_double * 6)()
         k = C.c_int32()
