@@ -35,10 +35,14 @@
 // the others take base + their rank in the run.
 // Counting step of the sort for entry i of cell c (all lanes of the wave call it; lanes that
 // are not live pass c = 0xffffffff): run detection across the wave, one atomic per run.
+// Entries of the trash cell (`trash` = its id: last step's ghosts, dead and departed entries of a
+// slab) are not counted: nothing ever places them, and their thousands of runs would all add to
+// one address.
 __device__ __forceinline__ void count_cell_runs(uint32_t c, bool live, int i,
                                                 uint32_t* __restrict__ cell_count,
-                                                uint32_t* __restrict__ slot)
+                                                uint32_t* __restrict__ slot, uint32_t trash)
 {
+   live = live && c != trash;
    const int lane = threadIdx.x & (SPH_WAVE - 1);
    const uint32_t prev = __shfl_up(c, 1);
    const bool head = (lane == 0) || (prev != c);
@@ -104,7 +108,7 @@ k_hash_count(const float4* __restrict__ posm, const float4* __restrict__ velp,
          vox[3 * i + 2] = cz;
       }
    }
-   count_cell_runs(c, live, i, cell_count, slot);
+   count_cell_runs(c, live, i, cell_count, slot, (uint32_t)g.ncells);
 }
 
 // ---- 2. exclusive scan of cell counts ------------------------------------------------------
@@ -242,12 +246,14 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
    if (tile_stats && i < TSTAT_COUNT && i != TSTAT_BLOCKS) tile_stats[i] = 0;
    const int n_in = meta[META_N_IN];
    if (i < n_in) {
-      const uint32_t c = key[i], first = cell_start[c], sl = slot[i];
-      perm[first + sl] = (uint32_t)i;
-      // the cell's first arrival lists it when it is too crowded for the per-member ranking scan
-      // (the trash cell's entries are dropped, not ranked)
-      if (sl == 0u && c != (uint32_t)ncells && cell_start[c + 1] - first > (uint32_t)RANK_BIG)
-         big_cells[1u + atomicAdd(&big_cells[0], 1u)] = c;
+      const uint32_t c = key[i];
+      if (c != (uint32_t)ncells) {   // (the trash cell's entries are dropped: no place, no rank)
+         const uint32_t first = cell_start[c], sl = slot[i];
+         perm[first + sl] = (uint32_t)i;
+         // the cell's first arrival lists it when it is too crowded for the per-member ranking scan
+         if (sl == 0u && cell_start[c + 1] - first > (uint32_t)RANK_BIG)
+            big_cells[1u + atomicAdd(&big_cells[0], 1u)] = c;
+      }
    }
    if (i == 0) {
       // Sorted ranges of the slab (kept out of a launch of their own: a kernel boundary costs
@@ -310,7 +316,8 @@ rank_gather(int p, int block_p0, uint32_t* __restrict__ lds_id, const uint32_t* 
             const float4* __restrict__ velp_in, float4* __restrict__ posm_out,
             float4* __restrict__ velp_out, uint32_t* __restrict__ remap = nullptr)
 {
-   const int n_in = meta[META_N_IN];
+   // positions [0, cell_start[trash]) hold the live entries; the trash cell's are not placed
+   const int n_in = (int)cell_start[trash];
    bool active = p < n_in;
    uint32_t i = 0, c = 0, s = 0, e = 0, id = 0;
    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

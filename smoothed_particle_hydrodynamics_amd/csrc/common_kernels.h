@@ -132,7 +132,7 @@ k_integrate(float4* __restrict__ posm, float4* __restrict__ velp, const float4* 
          key[p] = c;
       }
    }
-   if (HASH) count_cell_runs(c, live, p, cell_count, slot);
+   if (HASH) count_cell_runs(c, live, p, cell_count, slot, (uint32_t)g.ncells);
    // block reduction, fixed order
    __shared__ double s_ke[RED_THREADS / SPH_WAVE], s_pe[RED_THREADS / SPH_WAVE];
 #pragma unroll

@@ -685,7 +685,7 @@ __device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairC
       c = cell_of(g, x.x, x.y, x.z, cx, cy, cz);
       fs.key[p] = c;
    }
-   count_cell_runs(c, live, p, fs.cell_count, fs.slot);
+   count_cell_runs(c, live, p, fs.cell_count, fs.slot, (uint32_t)g.ncells);
    // block reduction, fixed order (the same as k_integrate's: same partial sums)
    __shared__ double s_ke[TILE_THREADS / SPH_WAVE], s_pe[TILE_THREADS / SPH_WAVE];
 #pragma unroll

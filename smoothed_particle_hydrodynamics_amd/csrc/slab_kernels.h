@@ -18,6 +18,22 @@ struct SlabMsg {
    float4 rec[1];  // [2 * capacity]: posm, velp pairs
 };
 
+// Record slot in a message for every lane that wants one: the wave's first such lane reserves the
+// wave's records with ONE atomic on the message's count word and the others take their place
+// behind it.  (One atomic per record - a hundred thousand of them on one address per message and
+// step - was most of both pack kernels' time.)  All lanes of the wave must call it.
+__device__ __forceinline__ int msg_reserve(int32_t* __restrict__ counter, bool want)
+{
+   const unsigned long long m = __ballot(want);
+   if (m == 0ull) return -1;
+   const int lane = threadIdx.x & (SPH_WAVE - 1);
+   const int leader = __ffsll((long long)m) - 1;
+   int base = 0;
+   if (lane == leader) base = atomicAdd(counter, __popcll(m));
+   base = __shfl(base, leader);
+   return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 // After integrate: classify every live entry of the sorted state.
 //   ghosts (outside the owned range)         -> dropped (re-sent by their owner every step)
 //   owned, now in plane <  lo + halo          -> copied to the left message
@@ -33,16 +49,23 @@ k_slab_pack(const float4* __restrict__ posm, float4* __restrict__ velp, int32_t*
             SlabMsg* __restrict__ left, SlabMsg* __restrict__ right, int capacity)
 {
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= meta[META_N_LIVE]) return;
-   float4 v = velp[p];
-   if (__float_as_uint(v.w) == SPH_DEAD_ID) return;
-   const bool owned = p >= meta[META_OWN_BEGIN] && p < meta[META_OWN_END];
-   bool drop = !owned;
+   const bool live = p < meta[META_N_LIVE];
+   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = v;
+   if (live) v = velp[p];
+   const bool alive = live && __float_as_uint(v.w) != SPH_DEAD_ID;
+   const bool owned = alive && p >= meta[META_OWN_BEGIN] && p < meta[META_OWN_END];
+   bool drop = alive && !owned;
+   bool to_left = false, to_right = false;
    if (owned) {
-      const float4 x = posm[p];
+      x = posm[p];
       const int plane = cell_coord(x.z, g.inv, g.nz_global);
-      if (have_left && plane < lo + halo) {
-         const int s = atomicAdd(&left->header[0], 1);
+      to_left = have_left && plane < lo + halo;
+      to_right = have_right && plane >= hi - halo;
+      drop = plane < g.z0 || plane >= g.z0 + g.nz;  // migrated beyond the halo
+   }
+   if (have_left) {
+      const int s = msg_reserve(&left->header[0], to_left);
+      if (to_left) {
          if (s < capacity) {
             left->rec[2 * s] = x;
             left->rec[2 * s + 1] = v;
@@ -50,8 +73,10 @@ k_slab_pack(const float4* __restrict__ posm, float4* __restrict__ velp, int32_t*
             atomicOr(&meta[META_ERRORS], 2);
          }
       }
-      if (have_right && plane >= hi - halo) {
-         const int s = atomicAdd(&right->header[0], 1);
+   }
+   if (have_right) {
+      const int s = msg_reserve(&right->header[0], to_right);
+      if (to_right) {
          if (s < capacity) {
             right->rec[2 * s] = x;
             right->rec[2 * s + 1] = v;
@@ -59,7 +84,6 @@ k_slab_pack(const float4* __restrict__ posm, float4* __restrict__ velp, int32_t*
             atomicOr(&meta[META_ERRORS], 2);
          }
       }
-      drop = plane < g.z0 || plane >= g.z0 + g.nz;  // migrated beyond the halo
    }
    if (drop) {
       v.w = __uint_as_float(SPH_DEAD_ID);
@@ -89,31 +113,43 @@ k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ ve
    const int lo_end = min(meta[META_BND_LO_END], oe);
    const int hi_begin = min(max(meta[META_BND_HI_BEGIN], lo_end), oe);
    const int n_left = lo_end - ob, n_right = oe - hi_begin;
-   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_left + n_right;
-        q += gridDim.x * blockDim.x) {
-      const int p = q < n_left ? ob + q : hi_begin + (q - n_left);
-      float4 x = posm[p];
-      float4 v = velp[p];
-      if (__float_as_uint(v.w) == SPH_DEAD_ID) continue;
-      double ke, pe;
-      integrate_particle<UNIT_SCALE>(k, x, v, acc[p], ke, pe);
-      const int plane = cell_coord(x.z, g.inv, g.nz_global);
-      if (zone.have_left && plane < zone.lo + zone.halo) {
-         const int s = atomicAdd(&left->header[0], 1);
-         if (s < capacity) {
-            left->rec[2 * s] = x;
-            left->rec[2 * s + 1] = v;
-         } else {
-            atomicOr(&meta[META_ERRORS], 2);
+   // (whole waves stay in the loop together: msg_reserve is a wave-wide operation)
+   for (int q0 = blockIdx.x * blockDim.x; q0 < n_left + n_right; q0 += gridDim.x * blockDim.x) {
+      const int q = q0 + threadIdx.x;
+      bool to_left = false, to_right = false;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f), v = x;
+      if (q < n_left + n_right) {
+         const int p = q < n_left ? ob + q : hi_begin + (q - n_left);
+         x = posm[p];
+         v = velp[p];
+         if (__float_as_uint(v.w) != SPH_DEAD_ID) {
+            double ke, pe;
+            integrate_particle<UNIT_SCALE>(k, x, v, acc[p], ke, pe);
+            const int plane = cell_coord(x.z, g.inv, g.nz_global);
+            to_left = zone.have_left && plane < zone.lo + zone.halo;
+            to_right = zone.have_right && plane >= zone.hi - zone.halo;
          }
       }
-      if (zone.have_right && plane >= zone.hi - zone.halo) {
-         const int s = atomicAdd(&right->header[0], 1);
-         if (s < capacity) {
-            right->rec[2 * s] = x;
-            right->rec[2 * s + 1] = v;
-         } else {
-            atomicOr(&meta[META_ERRORS], 2);
+      if (zone.have_left) {
+         const int s = msg_reserve(&left->header[0], to_left);
+         if (to_left) {
+            if (s < capacity) {
+               left->rec[2 * s] = x;
+               left->rec[2 * s + 1] = v;
+            } else {
+               atomicOr(&meta[META_ERRORS], 2);
+            }
+         }
+      }
+      if (zone.have_right) {
+         const int s = msg_reserve(&right->header[0], to_right);
+         if (to_right) {
+            if (s < capacity) {
+               right->rec[2 * s] = x;
+               right->rec[2 * s + 1] = v;
+            } else {
+               atomicOr(&meta[META_ERRORS], 2);
+            }
          }
       }
    }
