@@ -11,7 +11,7 @@
 #include "sph_device.h"
 
 #define SLAB_HEADER_INTS 8
-#define SLAB_PACK_BLOCKS 512   // fixed grid of the early pack (grid-stride over the border planes)
+#define SLAB_PACK_BLOCKS 4096  // fixed grid of the early pack (grid-stride over the border planes)
 
 struct SlabMsg {
    int32_t header[SLAB_HEADER_INTS];
