@@ -208,8 +208,9 @@ int sph_hip_set_timing_stride(sph_hip_context* ctx, int every);
  * (entries), out[14], out[15]: workgroups computed untiled in the density / acceleration pass,
  * out[16], out[17]: tile capacities the two passes were launched with, out[18]: 1 if the list
  * entries were in their wide format (a capacity above 4064), out[19]: neighbours per particle the
- * lists currently hold (starts at 254; doubled, up to 1022, when a step reports particles with
- * more - those are computed without a list, slower, same results). */
+ * lists currently hold (starts at 254; enlarged to 1022 - or to 510, if that is all the device has
+ * room for - when a step reports particles with more: those are computed without a list, slower,
+ * same results). */
 int sph_hip_get_tile_stats(sph_hip_context* ctx, int32_t out[20]);
 
 /* mKineticEnergyTotal / mPotentialEnergyTotal of the last integrate

@@ -258,24 +258,35 @@ int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, con
 // workgroups that will not fit them).
 // The density pass of an earlier step reported particles with more neighbours than their lists
 // hold (those lanes walk their candidates one by one in both passes, an order of magnitude
-// slower per particle): double the lists' capacity for the steps from here on.  The device has
+// slower per particle): enlarge the lists for the steps from here on.  The device has
 // to be idle for the exchange of the allocation - once or twice in a run that compresses.
 // Never changes results, only which route a particle takes.
 void grow_lists(sph_hip_context* ctx)
 {
-   const int want = ctx->list_cap * 2 + 2 > ctx->list_cap_max ? ctx->list_cap_max : ctx->list_cap * 2 + 2;
-   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;   // (reported by the step itself)
+   // the largest capacity the device has room for, at once (a second reallocation later would be
+   // a second stall); allocated while the device still works through the steps already enqueued
    uint32_t* bigger = nullptr;
-   const size_t words = ctx->list_blocks * list_rows(want) * TILE_THREADS;
-   if (dev_alloc(&bigger, words) != hipSuccess) {
+   int want = ctx->list_cap_max;
+   while (want > ctx->list_cap) {
+      const size_t words = ctx->list_blocks * list_rows(want) * TILE_THREADS;
+      if (dev_alloc(&bigger, words) == hipSuccess) break;
       (void)hipGetLastError();
+      bigger = nullptr;
+      want = (want / 2 - 1) & ~1;          // 1022 -> 510 -> 254
+   }
+   if (!bigger || want <= ctx->list_cap) {
+      if (bigger) (void)hipFree(bigger);
       ctx->list_cap_max = ctx->list_cap;   // no memory for it: stay, and do not ask again
       return;
    }
+   if (hipStreamSynchronize(ctx->stream) != hipSuccess) {   // (an error is reported by the step itself)
+      (void)hipFree(bigger);
+      return;
+   }
    (void)hipFree(ctx->nlist);
-   (void)hipMemsetAsync(bigger, 0, words * sizeof(uint32_t), ctx->stream);
    ctx->nlist = bigger;
    ctx->list_cap = want;
+   ctx->list_cap_max = want < ctx->list_cap_max ? want : ctx->list_cap_max;
    ((volatile int*)ctx->tile_feedback)[TSTAT_NO_LIST] = 0;
    static const bool debug = getenv("SPH_HIP_DEBUG") != nullptr;
    if (debug) fprintf(stderr, "sph_hip: neighbour lists enlarged to %d entries\n", want);

@@ -205,8 +205,8 @@ def test_full_any_list_capacity_same_bits(oracle, hiplib, monkeypatch, cap):
 
 def test_full_lists_grow_when_the_scene_compresses(oracle, hiplib, monkeypatch):
     """A column 11x denser than the benchmark's (what a breaking dam compresses to): most
-    particles have more than 254 neighbours.  The density pass reports them, the host doubles the
-    lists for the following steps (254 -> 510), and every step - before and after the change -
+    particles have more than 254 neighbours.  The density pass reports them, the host enlarges the
+    lists for the following steps (254 -> 1022), and every step - before and after the change -
     equals the oracle."""
     import smoothed_particle_hydrodynamics_amd as S
     from smoothed_particle_hydrodynamics_amd import scenes
