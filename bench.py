@@ -179,6 +179,17 @@ def phase_split(ctx, S, step, synchronize, set_timing, phase_totals, steps=5):
             "integrate": t[5] / k, "steps": k}
 
 
+def tile_summary(ts):
+    """What the last step's launches were sized for (sph_hip_get_tile_stats): LDS tile capacities
+    of the two passes (they decide the workgroups per CU), the largest tile, workgroups that went
+    the untiled route, entries per neighbour list."""
+    return {"capacity_density": ts["capacity_density"],
+            "capacity_acceleration": ts["capacity_acceleration"],
+            "largest_tile": ts["largest_tile"], "workgroups": ts["workgroups"],
+            "workgroups_untiled": [ts["untiled_density"], ts["untiled_acceleration"]],
+            "list_capacity": ts["list_capacity"]}
+
+
 def run_single(args, S, scenes, torch, local_rank):
     """N = 1: one context holds the whole grid."""
     n = args.particles
@@ -204,6 +215,7 @@ def run_single(args, S, scenes, torch, local_rank):
     sph.setTimingStride(1)
     totals = phase_split(sph, S, lambda: sph.step(), sph.synchronize, sph.setTiming, sph.phaseTotals)
     totals["pair_ms"] = pair[2] / covered
+    totals["tiles"] = tile_summary(sph.tileStats())
     nb_mean = float(sph.getParticles().mNeighborCount.mean())
     ke, pe = sph.energy()
     assert np.isfinite(ke) and np.isfinite(pe)
@@ -296,6 +308,7 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     slab.set_timing_stride(1)
     totals = phase_split(slab, S, stepper.step, fence, slab.set_timing, slab.phase_totals)
     totals["pair_ms"] = pair[2] / covered
+    totals["tiles"] = tile_summary(slab.tile_stats())
     d = slab.download()
     nb_mean = float(d["ncount"].mean())
     slab.close()
@@ -490,6 +503,7 @@ def main():
                 "acceleration": totals["acceleration"], "integrate": totals["integrate"],
                 "note": "%d fully instrumented steps after the timed region" % totals["steps"],
             },
+            "lds_tiles": totals.get("tiles"),
             "roofline": {
                 "bound": "hbm",
                 "kernel": "density+acceleration pass (k_full_density_tiled + k_full_accel_lists)",
