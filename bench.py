@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this image needs dmabuf IPC (RCCL P2P fails with
+# "hipIpcGetMemHandle: invalid argument" otherwise); exported already, kept here for safety
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -222,6 +226,7 @@ def run_single(args, S, scenes, torch, local_rank):
     return p, dt, totals, covered, n, nb_mean, "1 GPU"
 
 
+FALLBACK_GROUP = None               # gloo group of all ranks (N > 1): agreement channel + fallback transport
 C3_PARTICLES = 4 * 1024 * 1024      # BASELINE configs[2]
 C4_PARTICLES = 16 * 1024 * 1024     # BASELINE configs[3]: strong scaling over the node
 C5_PARTICLES = 64 * 1024 * 1024     # BASELINE configs[4]: 8:1:1 channel, long axis = slab axis
@@ -265,10 +270,24 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P);
     # =native lets libsph_hip.so issue the RCCL calls itself (no Python in the step loop)
     mode = os.environ.get("SPH_SLAB_TRANSPORT", "torch")
+    if mode == "torch" and FALLBACK_GROUP is not None:
+        # first contact with device-to-device P2P on this node: one small exchange with each
+        # neighbour; if any rank's fails, all ranks stage their messages through the host instead
+        # (agreed over gloo) and the JSON line says so - a slower number beats a crashed run
+        ok = SL.neighbour_exchange_works(rank, world, "cuda" if dist.get_backend() == "nccl" else "cpu")
+        if os.environ.get("SPH_BENCH_FORCE_P2P_FALLBACK") == "1":
+            ok = False
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=FALLBACK_GROUP)
+        if int(verdict.item()) == 0:
+            mode = "host-fallback"
     if mode == "native":
         stepper = SL.NativeSlabStepper(slab, rank, world)
     else:
-        transport = (SL.HostStagedTransport if mode == "host" else SL.DistTransport)(rank, world)
+        if mode == "host-fallback":
+            transport = SL.HostStagedTransport(rank, world, group=FALLBACK_GROUP)
+        else:
+            transport = (SL.HostStagedTransport if mode == "host" else SL.DistTransport)(rank, world)
         # cuts are re-evaluated every 500 steps (a count per rank; particles move only when the
         # fullest slab is 10 % over the mean), the message size every 256
         stepper = SL.DistSlabStepper(slab, transport, make_slab=make_slab, cuts=cuts,
@@ -319,7 +338,10 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
             "halo_message_bytes_allocated": SL.message_bytes(slab.msg_capacity),
             "parallelism": "z-slab x%d, RCCL halo (%s)" % (
                 world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so",
-                        "host": "host-staged rehearsal"}.get(mode, "torch.distributed P2P"))}
+                        "host": "host-staged rehearsal",
+                        "host-fallback": "HOST-STAGED FALLBACK over gloo: the device-to-device "
+                                         "P2P pre-flight failed on this node"}.get(
+                            mode, "torch.distributed P2P"))}
 
 
 def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup):
@@ -402,6 +424,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         dist.barrier()
+        global FALLBACK_GROUP
+        FALLBACK_GROUP = dist.new_group(backend="gloo")
         # strong (default): BASELINE configs[3] - 16M particles in the unit box cut in `world`
         # slabs; weak: `world` unit boxes in a row, --particles per GPU
         if args.scaling == "strong":

@@ -340,6 +340,40 @@ class NativeSlabStepper:
         return self.slab.comm_trim(slack, extra)
 
 
+def neighbour_exchange_works(rank, world, device, group=None, nbytes=4096):
+    """Pre-flight of the slab exchange: one small batch_isend_irecv with each neighbouring rank on
+    `device` ("cuda" for RCCL, "cpu" for gloo), checked for content.  Returns this rank's verdict
+    (an exception counts as "no": the caller agrees on a fallback over a group that does not need
+    the path under test, bench.py).  Collective in the sense that every rank must call it."""
+    import torch
+    import torch.distributed as dist
+    try:
+        mine = torch.full((nbytes,), (rank + 1) & 0xff, dtype=torch.uint8, device=device)
+        from_left, from_right = torch.zeros_like(mine), torch.zeros_like(mine)
+        ops = []
+        if rank > 0:
+            ops.append(dist.P2POp(dist.isend, mine, rank - 1, group))
+            ops.append(dist.P2POp(dist.irecv, from_left, rank - 1, group))
+        if rank + 1 < world:
+            ops.append(dist.P2POp(dist.isend, mine, rank + 1, group))
+            ops.append(dist.P2POp(dist.irecv, from_right, rank + 1, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if str(device).startswith("cuda"):
+            torch.cuda.synchronize()
+        ok = True
+        if rank > 0:
+            ok = ok and bool((from_left == (rank & 0xff)).all().item())
+        if rank + 1 < world:
+            ok = ok and bool((from_right == ((rank + 2) & 0xff)).all().item())
+        return ok
+    except Exception as exc:      # noqa: BLE001 - whatever the backend raises means "does not work"
+        import sys
+        print("slab exchange pre-flight failed on rank %d: %r" % (rank, exc), file=sys.stderr, flush=True)
+        return False
+
+
 class DistTransport:
     """Neighbour exchange over torch.distributed point-to-point ops (RCCL when the backend is
     "nccl": each slab pair has its own xGMI link).  One batch per step: send left/right,

@@ -222,3 +222,31 @@ def test_scene_subsets_match_the_whole_scene():
     sub = scenes.box_fill_subset(ids, (0.0, 0.0, 0.0), hi).reshape(-1, 3)
     assert np.array_equal(sub, pos.reshape(-1, 3)[ids])
     assert not vel.any() and (mass == 1.0).all()
+
+
+def _worker_preflight(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smoothed_particle_hydrodynamics_amd.slab import neighbour_exchange_works
+        ok = neighbour_exchange_works(rank, world, "cpu")
+        # a second group, as bench.py makes for the agreement and the fallback transport
+        other = dist.new_group(backend="gloo")
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=other)
+        ok2 = neighbour_exchange_works(rank, world, "cpu", group=other)
+        np.save(os.path.join(outdir, "ok%d.npy" % rank), np.array([ok, int(verdict.item()), ok2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_preflight_reports_a_working_path(tmp_path, world):
+    """bench.py's first contact with the neighbour exchange (one small batch_isend_irecv per
+    neighbour, content checked, verdicts agreed over a gloo group): on a working backend every
+    rank says yes, on the default group and on a second one."""
+    port = _free_port()
+    mp.spawn(_worker_preflight, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(os.path.join(str(tmp_path), "ok%d.npy" % r)).tolist() == [1, 1, 1]
