@@ -27,9 +27,12 @@
 extern "C" {
 #endif
 
-#define SPH_HIP_ABI_VERSION 4
+#define SPH_HIP_ABI_VERSION 5
 /* The ABI version the loaded library was built with (compare with SPH_HIP_ABI_VERSION of the
- * header the host was compiled against before calling anything else). */
+ * header the host was compiled against before calling anything else).  A library built with
+ * profiling hooks that cut pieces out of the kernels (diagnostic builds: results are garbage by
+ * design) ORs SPH_HIP_ABI_DIAGNOSTIC into the value, so that no host takes it for the product. */
+#define SPH_HIP_ABI_DIAGNOSTIC 0x4000
 int sph_hip_abi_version(void);
 
 typedef enum sph_hip_status {
@@ -47,8 +50,22 @@ typedef enum sph_hip_status {
  *          list-driven sums.  Integer outputs are identical to the reference's.
  *   FULL — every neighbour inside the interaction radius, found on a grid of cell edge
  *          >= h (27 cells), visited in ascending (cell id, particle index); per-pair
- *          arithmetic is the reference's (src/sph.cpp:737-761, 825-884). */
-typedef enum sph_hip_mode { SPH_HIP_MODE_REF = 0, SPH_HIP_MODE_FULL = 1 } sph_hip_mode;
+ *          arithmetic is the reference's (src/sph.cpp:737-761, 825-884).
+ *   FULL_FAST — FULL with tolerance-mode pair arithmetic (SPH_HIP_ARITH_FAST below): the same
+ *          neighbour sets (the exact fp32 test (dx*dx + dy*dy) + dz*dz < h^2 of
+ *          src/sph.cpp:641,653), the same canonical order and the viscous rescale inside the
+ *          neighbour loop (src/sph.cpp:880-882) - but the per-pair arithmetic evaluated the way
+ *          the reference's own shipped build may evaluate it (reference CMakeLists.txt:21:
+ *          -O3 -ffast-math -funsafe-math-optimizations -mfma): fused multiply-adds, h^2 - d^2
+ *          without the detour through sqrt (src/sph.cpp:744-750), an fp32 reciprocal in place of
+ *          the fp64 quotient of src/sph.cpp:854-856, hardware square root.  Neighbour counts are
+ *          identical to FULL; accelerations agree to 1e-4 relative (vector norm), densities to
+ *          1e-5 of the largest single-neighbour term; not bit-reproducible against the CPU. */
+typedef enum sph_hip_mode {
+   SPH_HIP_MODE_REF = 0,
+   SPH_HIP_MODE_FULL = 1,
+   SPH_HIP_MODE_FULL_FAST = 2
+} sph_hip_mode;
 
 /* The constants the hot path reads — the protected members SPH::SPH() initialises
  * (reference src/sph.h:149-210, src/sph.cpp:46-98).  Field order is ABI. */
@@ -115,6 +132,15 @@ const char* sph_hip_last_error(const sph_hip_context* ctx);
  * Takes effect at the start of the next phase call; grid shape and h may not change. */
 int sph_hip_set_params(sph_hip_context* ctx, const sph_hip_params* params);
 int sph_hip_get_params(const sph_hip_context* ctx, sph_hip_params* out);
+
+/* Pair arithmetic of a FULL-mode context (sph_hip_create with SPH_HIP_MODE_FULL_FAST starts in
+ * SPH_HIP_ARITH_FAST; slab contexts start exact).  May be changed between steps (synchronises);
+ * takes effect with the next cell build.  No counterpart in the reference's API: its counterpart
+ * is the compiler flags the reference is built with (CMakeLists.txt:21). */
+#define SPH_HIP_ARITH_EXACT 0
+#define SPH_HIP_ARITH_FAST 1
+int sph_hip_set_arithmetic(sph_hip_context* ctx, int arithmetic);
+int sph_hip_get_arithmetic(const sph_hip_context* ctx);
 
 /* ---- particle state ------------------------------------------------------------------- */
 

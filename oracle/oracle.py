@@ -191,6 +191,15 @@ class Oracle:
                                    _ptr(cs), _ptr(ci), _ptr(acc))
         return acc
 
+    def full_accel_scale(self, p, pos, vel, mass, rho):
+        """per particle: the magnitude sum of the terms its acceleration is made of (float64)"""
+        n = mass.size
+        _, cs, ci = self.full_cells(p, pos)
+        scale = np.zeros(n, np.float64)
+        self.lib.oracle_full_accel_scale(C.byref(p), n, _ptr(pos), _ptr(vel), _ptr(mass), _ptr(rho),
+                                         _ptr(cs), _ptr(ci), scale.ctypes.data_as(C.c_void_p))
+        return scale
+
 
 def reference_available():
     if not os.path.exists(REF_SO):

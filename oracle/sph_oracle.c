@@ -582,6 +582,54 @@ void oracle_full_accel(const sph_oracle_params* p, int n, const float* pos, cons
    }
 }
 
+/* How large the terms are that a particle's acceleration is the sum of (test infrastructure for
+ * the tolerance-mode kernels; no counterpart in the reference).  computeAcceleration adds and
+ * subtracts ~30 pair terms of either sign per particle (src/sph.cpp:866-882); where they cancel,
+ * ANY evaluation that is not bit-for-bit the reference's - its own -ffast-math build included -
+ * differs from it by rounding errors of the TERMS, not of the small sum.  scale[i] = sum over the
+ * neighbours of |pressure term| + the viscous terms' magnitudes carried through the same in-loop
+ * rescale + |point-mass gravity| (+ |uniform gravity|), in double: what a per-particle relative
+ * error has to be read against. */
+void oracle_full_accel_scale(const sph_oracle_params* p, int n, const float* pos, const float* vel,
+                             const float* mass, const float* rho, const int32_t* cell_start,
+                             const int32_t* cell_items, double* scale)
+{
+   for (int i = 0; i < n; i++) {
+      accel_state s;
+      accel_begin(p, &s, pos + 3 * i, vel + 3 * i, rho[i]);
+      double pg = 0.0, vt = 0.0;
+      FULL_FOR_EACH_NEIGHBOR({
+         const float mj = mass[q];
+         const float rhoj = rho[q];
+         const double pj = (double)((rhoj - p->rho0) * p->stiffness);
+         const double rhoj_inv = (rhoj > 0.0f) ? 1.0 / (double)rhoj : 1.0;
+         const double r = sqrt((double)dot) * (double)p->sim_scale;
+         const double hd = (double)p->hscaled - (double)d;
+         pg += fabs((double)p->kernel2 * r / ((double)d + 0.01) * hd * hd * (double)mj *
+                    (double)s.pi_div_rhoi2 * pj * rhoj_inv * rhoj_inv);
+         double dv = 0.0;
+         for (int c = 0; c < 3; c++) {
+            const double t = (double)vel[3 * (size_t)q + c] - (double)s.vi[c];
+            dv += t * t;
+         }
+         vt += sqrt(dv) * fabs(hd * rhoj_inv * (double)mj * (double)p->kernel3);
+         vt *= fabs((double)p->viscosity * (double)s.rhoi_inv);
+      });
+      double g = 0.0;
+      for (int c = 0; c < 3; c++) {
+         const double t = ((double)s.r[c] - (double)p->central_pos[c]) * (double)p->sim_scale;
+         g += t * t;
+      }
+      g = sqrt(g);
+      const double d3 = (g + (double)p->softening) * (g + (double)p->softening) * (g + (double)p->softening);
+      double t = pg + vt + fabs((double)p->grav_const * (double)p->central_mass) * g / d3;
+      if (p->apply_gravity)
+         t += sqrt((double)p->gravity[0] * p->gravity[0] + (double)p->gravity[1] * p->gravity[1] +
+                   (double)p->gravity[2] * p->gravity[2]);
+      scale[i] = t;
+   }
+}
+
 void oracle_step_full(const sph_oracle_params* p, int n, float* pos, float* vel, const float* mass,
                       float* rho, float* acc, int32_t* counts, float* ke, float* pe)
 {

@@ -5,6 +5,6 @@
 point raises."""
 from .build import build_library, library_path  # noqa: F401
 from .lib import SphParams, load_library, SphHipError, default_params  # noqa: F401
-from .sph import SPH, Particle, MODE_REF, MODE_FULL  # noqa: F401
+from .sph import SPH, Particle, MODE_REF, MODE_FULL, MODE_FULL_FAST, ARITH_EXACT, ARITH_FAST  # noqa: F401
 from .lib import TIMING_OFF, TIMING_SUMS, TIMING_PHASES  # noqa: F401
 from . import scenes  # noqa: F401

@@ -40,7 +40,7 @@ __device__ __forceinline__ void row_ranges(const CellGrid& g, const uint32_t* __
 // ---- density, untiled: one thread per particle, candidates read through L1/L2 -------------------
 // Used for workgroups whose LDS tile or neighbour lists would overflow (called inline from the
 // tiled kernels of full_tiled.h), for SPH_HIP_UNTILED=1, and as an independent cross-check.
-template <bool UNIT_SCALE>
+template <bool UNIT_SCALE, bool FAST = false>
 __device__ __forceinline__ void density_untiled(int p, const float4* __restrict__ posm,
                                                 const uint32_t* __restrict__ cell_start,
                                                 const float4* __restrict__ velp, const CellGrid& g,
@@ -68,22 +68,26 @@ __device__ __forceinline__ void density_untiled(int p, const float4* __restrict_
          float dx, dy, dz;
          const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
          if (d2 < k.h2) {
-            float d = sqrtf(d2);
-            if (!UNIT_SCALE) d *= k.sim_scale;
-            density_accumulate(k, pj.w, d, density);
+            if (FAST) {
+               density_accumulate_fast<UNIT_SCALE>(k, pj.w, d2, density);
+            } else {
+               float d = sqrtf(d2);
+               if (!UNIT_SCALE) d *= k.sim_scale;
+               density_accumulate(k, pj.w, d, density);
+            }
             count++;
          }
       }
    }
    rho[p] = density;
-   const float2 bc = neighbor_terms(k, density, pi.w);
+   const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
    const float4 v = velp[p];
    velB[p] = make_float4(v.x, v.y, v.z, bc.x);
    auxc[p] = bc.y;
    ncount[p] = count;
 }
 
-template <bool UNIT_SCALE>
+template <bool UNIT_SCALE, bool FAST>
 __global__ void __launch_bounds__(256)
 k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cell_start,
                const float4* __restrict__ velp, const int32_t* __restrict__ meta, CellGrid g,
@@ -92,11 +96,11 @@ k_full_density(const float4* __restrict__ posm, const uint32_t* __restrict__ cel
 {
    const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= meta[META_SUM_END]) return;
-   density_untiled<UNIT_SCALE>(p, posm, cell_start, velp, g, k, rho, velB, auxc, ncount);
+   density_untiled<UNIT_SCALE, FAST>(p, posm, cell_start, velp, g, k, rho, velB, auxc, ncount);
 }
 
 // ---- acceleration, untiled ------------------------------------------------------------------------
-template <bool UNIT_SCALE>
+template <bool UNIT_SCALE, bool FAST = false>
 __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ posm,
                                               const float4* __restrict__ velB,
                                               const float* __restrict__ rho,
@@ -125,17 +129,20 @@ __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ 
          float dx, dy, dz;
          const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
          if (d2 < k.h2) {
+            const float4 vj = velB[q];
             float d = sqrtf(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
-            const float4 vj = velB[q];
-            accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w, vj.x, vj.y, vj.z, vj.w, auxc[q]);
+            if (FAST)
+               accel_pair_fast<UNIT_SCALE>(k, s, dx, dy, dz, d, vj.x, vj.y, vj.z, vj.w, auxc[q]);
+            else
+               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w, vj.x, vj.y, vj.z, vj.w, auxc[q]);
          }
       }
    }
    acc[p] = accel_end<UNIT_SCALE>(k, s);
 }
 
-template <bool UNIT_SCALE>
+template <bool UNIT_SCALE, bool FAST>
 __global__ void __launch_bounds__(256)
 k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
              const float* __restrict__ rho, const float* __restrict__ auxc,
@@ -146,5 +153,5 @@ k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
    // acceleration is only needed for owned particles
    const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
    if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) return;
-   accel_untiled<UNIT_SCALE>(p, posm, velB, rho, auxc, cell_start, g, k, acc);
+   accel_untiled<UNIT_SCALE, FAST>(p, posm, velB, rho, auxc, cell_start, g, k, acc);
 }

@@ -26,6 +26,14 @@
 #include "common_kernels.h"
 #include "full_kernels.h"
 
+// SPH_ABLATE=N cuts a piece out of a kernel so that tools/ablate.py can price it: such a build
+// computes garbage.  It only compiles as a declared diagnostic build (tools/build_variant.sh adds
+// -DSPH_DIAGNOSTIC_BUILD), and a diagnostic build reports itself through sph_hip_abi_version(), which
+// the Python binding refuses unless SPH_HIP_ALLOW_DIAGNOSTIC=1: no test or bench loads one by accident.
+#if defined(SPH_ABLATE) && !defined(SPH_DIAGNOSTIC_BUILD)
+#error "SPH_ABLATE is for diagnostic builds only: add -DSPH_DIAGNOSTIC_BUILD (tools/build_variant.sh does)"
+#endif
+
 // The tile lives in dynamic LDS: its capacity (candidate positions per workgroup) is a launch
 // parameter, chosen by the host from the tile sizes the previous steps needed, because the
 // workgroups a CU can hold (and with them the latency hiding of both passes) is set by the LDS
@@ -358,7 +366,7 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
 // column of the workgroup's list block in global memory; SUM then walks that list once.  The
 // list doubles as the input of the acceleration pass.  A workgroup in which some particle has
 // more than NLIST_CAP neighbours gives up (flag) and runs the untiled code inline instead.
-template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE>
+template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
 __global__ void __launch_bounds__(TILE_THREADS, DENSITY_BLOCKS)
 k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
                      const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
@@ -388,8 +396,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    if ((int)blockIdx.x < tile_stats[TSTAT_GIVEUP_DENSITY]) {
       const int gp = begin + (int)giveup[blockIdx.x] * TILE_THREADS + tid;
       if (gp < end)
-         density_untiled<UNIT_SCALE>(gp, posm, cell_start, velp, g, k, rho_out, velB_out, auxc_out,
-                                     ncount);
+         density_untiled<UNIT_SCALE, FAST>(gp, posm, cell_start, velp, g, k, rho_out, velB_out,
+                                           auxc_out, ncount);
    }
    // (the mapping spreads the workgroups that exist over the XCDs: a slab context launches one
    // workgroup per 256 particles of its CAPACITY, and dealing eighths of that grid left the XCDs
@@ -537,9 +545,13 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
                float mj = pi.w;
                if (!UNIFORM_MASS) mj = posm[t - D].w;
-               float d = sqrt_rn(d2);
-               if (!UNIT_SCALE) d *= k.sim_scale;
-               density_accumulate(k, mj, d, density);
+               if (FAST) {
+                  density_accumulate_fast<UNIT_SCALE>(k, mj, d2, density);
+               } else {
+                  float d = sqrt_rn(d2);
+                  if (!UNIT_SCALE) d *= k.sim_scale;
+                  density_accumulate(k, mj, d, density);
+               }
                count++;
             }
          }
@@ -570,9 +582,13 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
             if (d2 < k.h2) {             // the reference's own test, on the reference's own value
-               float d = sqrt_rn(d2);
-               if (!UNIT_SCALE) d *= k.sim_scale;
-               density_accumulate(k, mj, d, density);
+               if (FAST) {
+                  density_accumulate_fast<UNIT_SCALE>(k, mj, d2, density);
+               } else {
+                  float d = sqrt_rn(d2);
+                  if (!UNIT_SCALE) d *= k.sim_scale;
+                  density_accumulate(k, mj, d, density);
+               }
             } else {
                screened_wrongly = true;  // passed the fused screen only: not a neighbour
             }
@@ -606,7 +622,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    }
    if (live) {
       rho_out[p] = density;
-      const float2 bc = neighbor_terms(k, density, pi.w);
+      const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
       const float4 v = velp[p];
       velB_out[p] = make_float4(v.x, v.y, v.z, bc.x);  // what the acceleration pass gathers
       auxc_out[p] = bc.y;                              // ... and what it stages in its tile
@@ -712,7 +728,7 @@ __device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairC
    __syncthreads();
 }
 
-template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE>
+template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
 __global__ void __launch_bounds__(TILE_THREADS, ACCEL_BLOCKS)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
                    const float* __restrict__ rho, const float* __restrict__ auxc,
@@ -726,6 +742,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 {
    __shared__ AccelLds L;
    float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
+   constexpr int BATCH = TILE_BATCH;
 
    const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
    const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
@@ -751,7 +768,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
       const int gp = g0 + tid;
       const bool mine = gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta);
-      if (mine) accel_untiled<UNIT_SCALE>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
+      if (mine) accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
       if (fs.on) {
          float4 gx = make_float4(0.f, 0.f, 0.f, 0.f), ga = gx;
          if (mine) {
@@ -774,10 +791,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // Prologue order: the first batch of tile loads is issued, then - while it is in flight - the
    // lanes' own loads go out; only then are the tile's entries stored to LDS.  Unconditional loads, index clamped into the tile (see
    // tile_load).
-   float4 buf[TILE_BATCH];
-   float cbuf[TILE_BATCH];
+   float4 buf[BATCH];
+   float cbuf[BATCH];
 #pragma unroll
-   for (int r = 0; r < TILE_BATCH; r++) {
+   for (int r = 0; r < BATCH; r++) {
       const int idx = min(tid + r * TILE_THREADS, total - 1);
       int d = D[0];
 #pragma unroll
@@ -807,22 +824,22 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 
    // the tile: first batch from the registers, then whatever is left
 #pragma unroll
-   for (int r = 0; r < TILE_BATCH; r++) {
+   for (int r = 0; r < BATCH; r++) {
       const int idx = tid + r * TILE_THREADS;
       if (idx < total) xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
    }
-   for (int base = TILE_BATCH * TILE_THREADS; base < total; base += TILE_BATCH * TILE_THREADS) {
+   for (int base = BATCH * TILE_THREADS; base < total; base += BATCH * TILE_THREADS) {
 #pragma unroll
-      for (int r = 0; r < TILE_BATCH; r++) {
+      for (int r = 0; r < BATCH; r++) {
          const int idx = min(base + tid + r * TILE_THREADS, total - 1);
          int d = D[0];
 #pragma unroll
          for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
          buf[r] = posm[idx - d];
          cbuf[r] = auxc[idx - d];
-      }
+         }
 #pragma unroll
-      for (int r = 0; r < TILE_BATCH; r++) {
+      for (int r = 0; r < BATCH; r++) {
          const int idx = base + tid + r * TILE_THREADS;
          if (idx < total) xyzc[idx] = make_float4(buf[r].x, buf[r].y, buf[r].z, cbuf[r]);
       }
@@ -864,7 +881,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          vj[u] = velB[qq];
 #endif
          mj[u] = pi.w;
-         if (!UNIFORM_MASS) mj[u] = posm[qq].w;
+         if (!UNIFORM_MASS && !FAST) mj[u] = posm[qq].w;   // (FAST: the mass rides in B)
       }
       // the next trip's list entries travel while this trip's pairs are computed
 #pragma unroll
@@ -883,8 +900,11 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #if defined(SPH_ABLATE) && SPH_ABLATE == 22
             s.pgx += d + vj[u].x + pj.w;   // timing only: no pair arithmetic
 #else
-            accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
-                                   pj.w, in_range);
+            if (FAST)
+               accel_pair_fast<UNIT_SCALE>(k, s, dx, dy, dz, d, vj[u].x, vj[u].y, vj[u].z, vj[u].w, pj.w);
+            else
+               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
+                                      pj.w, in_range);
 #endif
          }
       }
@@ -905,12 +925,16 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
+               const float4 vj = velB[t - D];
                float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
-               const float4 vj = velB[t - D];
-               float mj = pi.w;
-               if (!UNIFORM_MASS) mj = posm[t - D].w;
-               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, vj.w, pj.w, in_range);
+               if (FAST) {
+                  accel_pair_fast<UNIT_SCALE>(k, s, dx, dy, dz, d, vj.x, vj.y, vj.z, vj.w, pj.w);
+               } else {
+                  float mj = pi.w;
+                  if (!UNIFORM_MASS) mj = posm[t - D].w;
+                  accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, vj.w, pj.w, in_range);
+               }
             }
          }
       }

@@ -19,6 +19,29 @@ __device__ __forceinline__ void density_accumulate(const PairConsts& k, float ma
    }
 }
 
+// ---- tolerance mode (SPH_HIP_MODE_FULL_FAST) ----------------------------------------------------
+// The reference ships with -O3 -ffast-math -funsafe-math-optimizations -mfma
+// (reference CMakeLists.txt:21): its own binary is not the IEEE evaluation of src/sph.cpp - the
+// survey measured 2.1e-5 relative on accelerations between the two builds - and the north star's
+// bar is 1e-4 relative on forces.  The FAST variants keep what decides WHICH pairs are summed and
+// in WHICH order (the exact unfused d2 < h2 membership test, the canonical order, the rescale of the
+// viscous sum inside the neighbour loop) and evaluate the per-pair arithmetic the way such a build
+// may: fused multiply-adds, no detour through the square root where only d^2 is needed
+// (computeDensity), fp32 reciprocal instead of the fp64 quotient of src/sph.cpp:854-856.  Every fused operation is written out (the translation unit is compiled with
+// -ffp-contract=off), so all routes - tiled, untiled, the walk of a particle without a list, any
+// slab count - produce the same bits as each other.
+
+// computeDensity's inner term from the squared distance: t = h^2 - d^2 without sqrt and re-squaring.
+// d2 is the reference's unfused (dx*dx + dy*dy) + dz*dz, already known to be < h2.
+template <bool UNIT_SCALE>
+__device__ __forceinline__ void density_accumulate_fast(const PairConsts& k, float mass, float d2,
+                                                        float& density)
+{
+   float t = UNIT_SCALE ? (k.hscaled2 - d2) : __builtin_fmaf(-d2, k.sim_scale * k.sim_scale, k.hscaled2);
+   const float w = (t * t) * t;
+   density = __builtin_fmaf(mass * k.kernel1, w, density);
+}
+
 // Quantities of neighbour j that computeAcceleration re-derives for every pair
 // (reference src/sph.cpp:829-834, 860, 871).  They depend on j only, so they are computed once
 // per particle after the density pass: B = p_j * rhojInv^2, C = (rhojInv * m_j) * k3.
@@ -65,8 +88,16 @@ __device__ __forceinline__ void div3_shared_den(float nx, float ny, float nz, do
    }
 }
 
+// FAST contexts: {m_j * B, C} (the mass rides in both factors)
+__device__ __forceinline__ float2 neighbor_terms_fast(const PairConsts& k, float rho_j, float m_j)
+{
+   const float2 bc = neighbor_terms(k, rho_j, m_j);
+   return make_float2(m_j * bc.x, bc.y);
+}
+
 struct AccelState {
    float rhoi_inv, pi_div_rhoi2, visc_scale;
+   float k2a;   // FAST: kernel2 * A (* sim_scale): what multiplies r / den in the pressure term
    float rx, ry, rz, vx, vy, vz;
    float pgx, pgy, pgz, vtx, vty, vtz;
 };
@@ -80,6 +111,7 @@ __device__ __forceinline__ void accel_begin(const PairConsts& k, AccelState& s, 
    const float rhoi_inv2 = s.rhoi_inv * s.rhoi_inv;
    s.pi_div_rhoi2 = pi * rhoi_inv2;
    s.visc_scale = k.viscosity * s.rhoi_inv;
+   s.k2a = k.kernel2 * s.pi_div_rhoi2 * k.sim_scale;
    s.rx = posm.x; s.ry = posm.y; s.rz = posm.z;
    s.vx = velp.x; s.vy = velp.y; s.vz = velp.z;
    s.pgx = s.pgy = s.pgz = 0.0f;
@@ -128,6 +160,35 @@ __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, f
    s.vtx *= s.visc_scale;
    s.vty *= s.visc_scale;
    s.vtz *= s.visc_scale;
+}
+
+// One neighbour, tolerance mode (see the top of this file): same terms, same place of the viscous
+// rescale; fp32 reciprocal for g = (k2 * r) / (d + 0.01) in place of the fp64 quotient, fused
+// accumulation.  (dx,dy,dz) = r_i - r_j and d = the stored distance exactly as in accel_pair - the
+// correctly rounded root of the unfused d2: both sums hang on h - d, which for a neighbour near
+// the rim of the kernel is a difference of nearly equal numbers, and the viscous sum is dominated
+// by its LAST neighbour (every earlier one is rescaled once more, :880-882), so an ulp of d there
+// is a relative error of ulp * h / (h - d) in the whole term - measured 1.5e-3 on accelerations
+// with a hardware square root on the fused d2.
+// Bm = m_j * B: the density pass of a FAST context stores the product (neighbor_terms_fast), so no
+// route of the acceleration pass gathers masses.
+template <bool UNIT_SCALE>
+__device__ __forceinline__ void accel_pair_fast(const PairConsts& k, AccelState& s, float dx, float dy,
+                                                float dz, float d, float vjx, float vjy, float vjz,
+                                                float Bm, float C)
+{
+   const float rden = __builtin_amdgcn_rcpf(d + 0.01f);
+   const float hd = k.hscaled - d;
+   // pressure: (k2 * r / den) * (h - d)^2 * (m_j * A) * B
+   const float f = ((hd * hd) * rden) * (s.k2a * Bm);
+   s.pgx = __builtin_fmaf(dx, f, s.pgx);
+   s.pgy = __builtin_fmaf(dy, f, s.pgy);
+   s.pgz = __builtin_fmaf(dz, f, s.pgz);
+   // viscosity, rescaled inside the neighbour loop (:880-882)
+   const float c2 = hd * C;
+   s.vtx = __builtin_fmaf(vjx - s.vx, c2, s.vtx) * s.visc_scale;
+   s.vty = __builtin_fmaf(vjy - s.vy, c2, s.vty) * s.visc_scale;
+   s.vtz = __builtin_fmaf(vjz - s.vz, c2, s.vtz) * s.visc_scale;
 }
 
 // reference src/sph.cpp:888-933

@@ -166,6 +166,7 @@ struct sph_hip_context {
    struct TileDesc* tile_desc = nullptr; // per 256-particle workgroup: LDS tile layout
    uint32_t* nlist = nullptr;            // neighbour lists density pass -> acceleration pass
    uint32_t* nlist_overflow = nullptr;   // per workgroup: 1 = tile or a list did not fit
+   int fast = 0;                   // tolerance-mode pair arithmetic (SPH_HIP_MODE_FULL_FAST / sph_hip_set_arithmetic)
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
    int prehashed = 0;              // the last integrate also did the next build's cell hash + counts

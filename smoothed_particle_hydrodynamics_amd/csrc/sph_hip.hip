@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <new>
+#include <type_traits>
 
 #include "cell_build.h"
 #include "common_kernels.h"
@@ -24,6 +25,16 @@ namespace {
 std::string g_create_error;
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// run-time flags -> template arguments: f(std::bool_constant..., one per flag)
+template <class F>
+void bind_flags(F&& f) { f(); }
+template <class F, class... Rest>
+void bind_flags(F&& f, bool flag, Rest... rest)
+{
+   if (flag) bind_flags([&](auto... later) { f(std::true_type{}, later...); }, rest...);
+   else bind_flags([&](auto... later) { f(std::false_type{}, later...); }, rest...);
+}
 
 PairConsts pair_consts(const sph_hip_params& p)
 {
@@ -207,16 +218,15 @@ int tile_levels(Kernel kernel, int bytes_per_entry, int* levels, int* per_cu)
 void allow_large_tiles()
 {
    const int most = 160 * 1024;
-#define SPH_ALLOW(K) (void)hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, most)
-#define SPH_ALLOW_ALL(K)                                                                         \
-   SPH_ALLOW((K<true, true, false>)); SPH_ALLOW((K<true, false, false>));                         \
-   SPH_ALLOW((K<false, true, false>)); SPH_ALLOW((K<false, false, false>));                       \
-   SPH_ALLOW((K<true, true, true>)); SPH_ALLOW((K<true, false, true>));                           \
-   SPH_ALLOW((K<false, true, true>)); SPH_ALLOW((K<false, false, true>))
-   SPH_ALLOW_ALL(k_full_density_tiled);
-   SPH_ALLOW_ALL(k_full_accel_lists);
-#undef SPH_ALLOW_ALL
-#undef SPH_ALLOW
+   for (int m = 0; m < 16; m++) {
+      bind_flags([&](auto U, auto M, auto W, auto F) {
+         (void)hipFuncSetAttribute((const void*)(k_full_density_tiled<U.value, M.value, W.value, F.value>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         if constexpr (M.value || !F.value)   // (FAST never gathers masses: only its M = true form exists)
+            (void)hipFuncSetAttribute((const void*)(k_full_accel_lists<U.value, M.value, W.value, F.value>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, most);
+      }, (m & 1) != 0, (m & 2) != 0, (m & 4) != 0, (m & 8) != 0);
+   }
    (void)hipGetLastError();
 }
 
@@ -302,10 +312,18 @@ void pick_tile_caps(sph_hip_context* ctx)
    }
    if (caps.n_cand == 0) {
       allow_large_tiles();
-      ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true, false>, DENSITY_TILE_BYTES,
-                                          ctx->density_levels, ctx->density_per_cu);
-      ctx->n_accel_levels = tile_levels(k_full_accel_lists<true, true, false>, ACCEL_TILE_BYTES,
-                                        ctx->accel_levels, ctx->accel_per_cu);
+      if (ctx->fast)
+         ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true, false, true>, DENSITY_TILE_BYTES,
+                                             ctx->density_levels, ctx->density_per_cu);
+      else
+         ctx->n_density_levels = tile_levels(k_full_density_tiled<true, true, false, false>, DENSITY_TILE_BYTES,
+                                             ctx->density_levels, ctx->density_per_cu);
+      if (ctx->fast)
+         ctx->n_accel_levels = tile_levels(k_full_accel_lists<true, true, false, true>, ACCEL_TILE_BYTES,
+                                           ctx->accel_levels, ctx->accel_per_cu);
+      else
+         ctx->n_accel_levels = tile_levels(k_full_accel_lists<true, true, false, false>, ACCEL_TILE_BYTES,
+                                           ctx->accel_levels, ctx->accel_per_cu);
       // candidates = ascending union of both kernels' levels
       int nd = 0, na = 0;
       while ((nd < ctx->n_density_levels || na < ctx->n_accel_levels) && caps.n_cand < TILE_CANDS) {
@@ -475,23 +493,13 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
 {
    const int cap = ctx->caps.cap_density;
    const size_t lds = (size_t)(cap + TILE_PAD) * DENSITY_TILE_BYTES;
-#define SPH_GO3(U, M, W)                                                                         \
-   hipLaunchKernelGGL((k_full_density_tiled<U, M, W>), dim3(blocks), dim3(TILE_THREADS), lds,    \
-                      ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->cell_start,    \
-                      ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount,      \
-                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
-                      ctx->giveup_density, ctx->tile_feedback, ctx->list_cap)
-#define SPH_GO(U, M)                                                                             \
-   do {                                                                                          \
-      if (ctx->caps.wide) SPH_GO3(U, M, true);                                                   \
-      else SPH_GO3(U, M, false);                                                                 \
-   } while (0)
-   if (unit && ctx->uniform_mass) SPH_GO(true, true);
-   else if (unit) SPH_GO(true, false);
-   else if (ctx->uniform_mass) SPH_GO(false, true);
-   else SPH_GO(false, false);
-#undef SPH_GO
-#undef SPH_GO3
+   bind_flags([&](auto U, auto M, auto W, auto F) {
+      hipLaunchKernelGGL((k_full_density_tiled<U.value, M.value, W.value, F.value>), dim3(blocks),
+                         dim3(TILE_THREADS), lds, ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur],
+                         ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc,
+                         ctx->ncount, ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap,
+                         ctx->tile_stats, ctx->giveup_density, ctx->tile_feedback, ctx->list_cap);
+   }, unit, ctx->uniform_mass != 0, ctx->caps.wide != 0, ctx->fast != 0);
 }
 
 void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part,
@@ -511,23 +519,15 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
    }
    const int cap = ctx->caps.cap_accel;
    const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
-#define SPH_GO(U, M)                                                                             \
-   do {                                                                                          \
-      if (ctx->caps.wide) SPH_GO3(U, M, true);                                                   \
-      else SPH_GO3(U, M, false);                                                                 \
-   } while (0)
-#define SPH_GO3(U, M, W)                                                                         \
-   hipLaunchKernelGGL((k_full_accel_lists<U, M, W>), dim3(blocks), dim3(TILE_THREADS), lds,      \
-                      st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,          \
-                      ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc,           \
-                      ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats,      \
-                      ctx->giveup_accel, part, ctx->list_cap, ctx->tile_feedback, fs)
-   if (unit && ctx->uniform_mass) SPH_GO(true, true);
-   else if (unit) SPH_GO(true, false);
-   else if (ctx->uniform_mass) SPH_GO(false, true);
-   else SPH_GO(false, false);
-#undef SPH_GO
-#undef SPH_GO3
+   // (a FAST context's density pass folds the mass into B: its acceleration pass never gathers masses)
+   bind_flags([&](auto U, auto M, auto W, auto F) {
+      if constexpr (M.value || !F.value)
+      hipLaunchKernelGGL((k_full_accel_lists<U.value, M.value, W.value, F.value>), dim3(blocks),
+                         dim3(TILE_THREADS), lds, st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,
+                         ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc, ctx->tile_desc,
+                         ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats, ctx->giveup_accel, part,
+                         ctx->list_cap, ctx->tile_feedback, fs);
+   }, unit, ctx->uniform_mass != 0 || ctx->fast != 0, ctx->caps.wide != 0, ctx->fast != 0);
 }
 
 int launch_density(sph_hip_context* ctx)
@@ -543,14 +543,12 @@ int launch_density(sph_hip_context* ctx)
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
          launch_density_tiled(ctx, unit, div_up(n, TILE_THREADS), k);  // give-up workgroups fall back inline
-      } else if (unit) {                               // SPH_HIP_UNTILED=1: untiled everywhere
-         hipLaunchKernelGGL(k_full_density<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
-                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount);
-      } else {
-         hipLaunchKernelGGL(k_full_density<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
-                            ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount);
+      } else {                                         // SPH_HIP_UNTILED=1: untiled everywhere
+         bind_flags([&](auto U, auto F) {
+            hipLaunchKernelGGL((k_full_density<U.value, F.value>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               ctx->posm[ctx->cur], ctx->cell_start, ctx->velp[ctx->cur], ctx->meta,
+                               ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc, ctx->ncount);
+         }, unit, ctx->fast != 0);
       }
    }
    SPH_TRY(hipGetLastError());
@@ -574,14 +572,12 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
          launch_accel_lists(ctx, unit, div_up(n, TILE_THREADS), k, part, part ? part_stream : ctx->stream, fused);
-      } else if (unit) {
-         hipLaunchKernelGGL(k_full_accel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                            ctx->meta, ctx->grid, k, ctx->acc);
       } else {
-         hipLaunchKernelGGL(k_full_accel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                            ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                            ctx->meta, ctx->grid, k, ctx->acc);
+         bind_flags([&](auto U, auto F) {
+            hipLaunchKernelGGL((k_full_accel<U.value, F.value>), dim3(blocks), dim3(256), 0, ctx->stream,
+                               ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
+                               ctx->meta, ctx->grid, k, ctx->acc);
+         }, unit, ctx->fast != 0);
       }
    }
    SPH_TRY(hipGetLastError());
@@ -761,7 +757,13 @@ __global__ void k_selftest_sqrt(unsigned long long* __restrict__ out)
 
 extern "C" {
 
+// (a diagnostic build - SPH_ABLATE hooks compiled in, garbage by design - says so here: the
+// Python binding refuses it unless SPH_HIP_ALLOW_DIAGNOSTIC=1)
+#ifdef SPH_DIAGNOSTIC_BUILD
+int sph_hip_abi_version(void) { return SPH_HIP_ABI_VERSION | SPH_HIP_ABI_DIAGNOSTIC; }
+#else
 int sph_hip_abi_version(void) { return SPH_HIP_ABI_VERSION; }
+#endif
 
 int sph_hip_selftest_sqrt(int device, uint64_t* mismatches, uint32_t* first_bad)
 {
@@ -840,10 +842,17 @@ int sph_hip_params_default(sph_hip_params* p, float h, int cells_x, int cells_y,
 static int create_impl(sph_hip_context** out, const sph_hip_params* params, int capacity, int mode,
                        int device, int plane_lo, int plane_hi, int halo)
 {
-   if (!out || !params || capacity < 1 || (mode != SPH_HIP_MODE_REF && mode != SPH_HIP_MODE_FULL)) {
+   if (!out || !params || capacity < 1 ||
+       (mode != SPH_HIP_MODE_REF && mode != SPH_HIP_MODE_FULL && mode != SPH_HIP_MODE_FULL_FAST)) {
       g_create_error = "sph_hip_create: invalid argument";
       return SPH_HIP_ERR_INVALID;
    }
+   // FULL with the tolerance-mode pair arithmetic (SPH_HIP_ARITH=fast: experiments run the tools
+   // that create plain FULL contexts - A/B, ablation, slab cost - in that mode)
+   const char* arith_env = getenv("SPH_HIP_ARITH");
+   const bool fast = mode == SPH_HIP_MODE_FULL_FAST ||
+                     (mode == SPH_HIP_MODE_FULL && arith_env && strcmp(arith_env, "fast") == 0);
+   if (fast) mode = SPH_HIP_MODE_FULL;
    *out = nullptr;
    int ndev = 0;
    hipError_t e = hipGetDeviceCount(&ndev);
@@ -856,6 +865,7 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    if (!ctx) return SPH_HIP_ERR_INVALID;
    ctx->prm = *params;
    ctx->mode = mode;
+   ctx->fast = fast ? 1 : 0;
    ctx->device = device;
    ctx->capacity = capacity;
 
@@ -1042,6 +1052,26 @@ int sph_hip_set_params(sph_hip_context* ctx, const sph_hip_params* p)
    ctx->prm = *p;
    return SPH_HIP_OK;
 }
+
+int sph_hip_set_arithmetic(sph_hip_context* ctx, int arithmetic)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || (arithmetic != SPH_HIP_ARITH_EXACT && arithmetic != SPH_HIP_ARITH_FAST)) {
+      ctx->err = "sph_hip_set_arithmetic: FULL-mode contexts; SPH_HIP_ARITH_EXACT or SPH_HIP_ARITH_FAST";
+      return SPH_HIP_ERR_INVALID;
+   }
+   if (ctx->fast == arithmetic) return SPH_HIP_OK;
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   ctx->fast = arithmetic;
+   // the capacity levels belong to the kernels that run: worked out again at the next cell build,
+   // and what the old kernels' levels reported means nothing for the new ones
+   ctx->caps.n_cand = 0;
+   if (ctx->tile_feedback) memset(ctx->tile_feedback, 0, TSTAT_COUNT * sizeof(int));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_get_arithmetic(const sph_hip_context* ctx) { return ctx ? ctx->fast : SPH_HIP_ERR_INVALID; }
 
 int sph_hip_get_params(const sph_hip_context* ctx, sph_hip_params* out)
 {

@@ -6,6 +6,9 @@ from .build import library_path
 
 MODE_REF = 0
 MODE_FULL = 1
+MODE_FULL_FAST = 2   # FULL with tolerance-mode pair arithmetic (include/sph_hip.h)
+ARITH_EXACT, ARITH_FAST = 0, 1
+ABI_DIAGNOSTIC = 0x4000
 # sph_hip_set_timing levels (include/sph_hip.h)
 TIMING_OFF, TIMING_SUMS, TIMING_PHASES = 0, 1, 2
 
@@ -61,6 +64,8 @@ PROTOTYPES = {
     "sph_hip_last_error": (C.c_char_p, [_ctx]),
     "sph_hip_set_params": (C.c_int, [_ctx, _P(SphParams)]),
     "sph_hip_get_params": (C.c_int, [_ctx, _P(SphParams)]),
+    "sph_hip_set_arithmetic": (C.c_int, [_ctx, C.c_int]),
+    "sph_hip_get_arithmetic": (C.c_int, [_ctx]),
     "sph_hip_upload": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sph_hip_download": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sph_hip_particle_count": (C.c_int, [_ctx]),
@@ -111,7 +116,7 @@ PROTOTYPES = {
     "sph_hip_abi_version": (C.c_int, []),
     "sph_hip_selftest_sqrt": (C.c_int, [C.c_int, _P(C.c_uint64), _P(C.c_uint32)]),
 }
-ABI_VERSION = 4   # SPH_HIP_ABI_VERSION of the include/sph_hip.h these prototypes mirror
+ABI_VERSION = 5   # SPH_HIP_ABI_VERSION of the include/sph_hip.h these prototypes mirror
 
 _LIB = None
 
@@ -146,9 +151,14 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.sph_hip_abi_version() != ABI_VERSION:
+    abi = lib.sph_hip_abi_version()
+    if abi & ABI_DIAGNOSTIC and os.environ.get("SPH_HIP_ALLOW_DIAGNOSTIC") != "1":
+        raise SphHipError("%s is a diagnostic build (profiling hooks that cut pieces out of the "
+                          "kernels: its results are garbage by design); only tools/ablate.py, with "
+                          "SPH_HIP_ALLOW_DIAGNOSTIC=1, may load one" % path)
+    if abi & ~ABI_DIAGNOSTIC != ABI_VERSION:
         raise SphHipError("%s has ABI version %d, this binding expects %d: rebuild it" %
-                          (path, lib.sph_hip_abi_version(), ABI_VERSION))
+                          (path, abi & ~ABI_DIAGNOSTIC, ABI_VERSION))
     _LIB = lib
     return lib
 

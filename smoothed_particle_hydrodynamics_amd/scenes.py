@@ -71,9 +71,11 @@ def dam_break_params(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32
     return p, [box[c] * fill[c] for c in range(3)]
 
 
-def dam_break(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0, seed=42):
+def dam_break(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0, seed=42, speed=0.0):
     """Dam-break column modelled on the reference's commented-out init (src/sph.cpp:328-345):
-    uniform random points in x<0.1*Lx, y<0.75*Ly, z<Lz, at rest, unit masses.
+    uniform random points in x<0.1*Lx, y<0.75*Ly, z<Lz, at rest, unit masses.  speed > 0: a seeded
+    uniform random velocity in [-speed, speed)^3 per particle instead of rest (parity tests: with
+    every particle at rest the viscous sum of src/sph.cpp:875-882 is identically zero).
 
     Returns (params, pos[3n], vel[3n], mass[n]).  The voxel grid (edge 2h) covers the box; the
     central point mass is switched off (it is the astrophysical part of the reference's
@@ -82,6 +84,8 @@ def dam_break(n, box=(1.0, 1.0, 1.0), fill=(0.1, 0.75, 1.0), neighbors=32.0, see
     p, hi = dam_break_params(n, box, fill, neighbors)
     pos = box_fill(n, (0.0, 0.0, 0.0), hi, seed)
     vel = np.zeros(3 * n, np.float32)
+    if speed > 0.0:
+        vel = box_fill(n, (-speed,) * 3, (speed,) * 3, seed + 1)
     mass = np.ones(n, np.float32)
     return p, pos, vel, mass
 

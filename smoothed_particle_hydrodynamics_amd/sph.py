@@ -10,9 +10,9 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import MODE_FULL, MODE_REF, SphHipError, SphParams, default_params, load_library
+from .lib import ARITH_EXACT, ARITH_FAST, MODE_FULL, MODE_FULL_FAST, MODE_REF, SphHipError, SphParams, default_params, load_library
 
-__all__ = ["SPH", "Particle", "MODE_REF", "MODE_FULL"]
+__all__ = ["SPH", "Particle", "MODE_REF", "MODE_FULL", "MODE_FULL_FAST", "ARITH_EXACT", "ARITH_FAST"]
 
 
 class Particle:
@@ -39,7 +39,8 @@ class SPH:
       * the particle count and the scene are arguments (the reference fixes N = M*1024 at
         compile time and always builds its sphere scene, src/sph.cpp:59,117);
       * `mode` selects the shipped sampled search (MODE_REF) or complete neighbourhoods
-        (MODE_FULL);
+        (MODE_FULL; MODE_FULL_FAST = the same neighbourhoods and order with tolerance-mode pair
+        arithmetic, see include/sph_hip.h);
       * the host `Particle` mirror is refreshed by `syncParticles()` / `getParticles()`
         rather than being written by every phase.
     """
@@ -235,6 +236,14 @@ class SPH:
 
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
+
+    def setArithmetic(self, arithmetic):
+        """ARITH_EXACT / ARITH_FAST for the pair sums of a FULL-mode context (sph_hip_set_arithmetic)."""
+        self._check(self._lib.sph_hip_set_arithmetic(self._ctx, int(arithmetic)), "sph_hip_set_arithmetic")
+        self._mirror_fresh = False
+
+    def getArithmetic(self):
+        return self._lib.sph_hip_get_arithmetic(self._ctx)
 
     # ---- protected pipeline (reference src/sph.h:96-112) ----------------------------------------
     def voxelizeParticles(self):

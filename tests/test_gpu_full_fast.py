@@ -1,0 +1,192 @@
+"""GPU parity, FULL mode with tolerance-mode pair arithmetic (SPH_HIP_MODE_FULL_FAST).
+
+The reference's shipped binary is built with -O3 -ffast-math -funsafe-math-optimizations -mfma
+(reference CMakeLists.txt:21): it is not the IEEE evaluation of src/sph.cpp (2.1e-5
+relative between the two on accelerations).  FAST mode keeps what decides which pairs are summed
+and in which order - the exact membership test of src/sph.cpp:641,653, the canonical order, the
+viscous rescale inside the loop (:880-882) - and relaxes the per-pair arithmetic (csrc/pair_math.h).
+
+Bar (against the CPU oracle, every step started from the SAME state on both sides):
+  * neighbour counts identical;
+  * acceleration: |a - a_ref| <= 1e-4 * max(|a|, |a_ref|) per particle (the north star's tolerance),
+    read against what the acceleration is a sum OF: a particle's ~30 pair terms of either sign
+    (src/sph.cpp:866-882) largely cancel in a fluid near rest, and where they cancel to less than
+    a hundredth of their magnitude sum T (oracle_full_accel_scale), any evaluation that is not the
+    reference's bit for bit - the reference's own -ffast-math build included - differs from it by
+    rounding errors of the terms.  Such a particle passes with |a - a_ref| <= 1e-6 * T (16 fp32
+    ulps of the magnitude sum); at most 0.5 % of a scene's particles may need that clause;
+  * density: |rho - rho_ref| <= 1e-5 * k1 * m_max * h^6 (the largest single-neighbour term: SURVEY.md
+    section 4 asks for an absolute tolerance on that scale, since rho sums terms that vanish at the
+    kernel's edge) + 2e-6 * |rho_ref|;
+  * new velocity within 1e-4 (vector norm, relative), new position within 1e-6 of the cell edge
+    (+ 2 ulps of the coordinate).
+The exact mode (tests/test_gpu_full_mode.py) stays the bit-for-bit gate.
+"""
+import numpy as np
+import pytest
+
+from helpers import to_oracle_params, vec_rel
+
+pytestmark = pytest.mark.gpu
+
+FORCE_RTOL = 1e-4
+FORCE_COND_TOL = 1e-6      # of the magnitude sum of a particle's terms
+FORCE_COND_SHARE = 0.005   # particles that may need the second clause
+DENSITY_TERM_TOL = 1e-5
+DENSITY_RTOL = 2e-6
+
+
+def check_fast(part, ref, p, mass, what="", scale=None):
+    assert np.array_equal(part.mNeighborCount, ref["ncount"]), "%s neighbour counts differ at %d particles" % (
+        what, int((part.mNeighborCount != ref["ncount"]).sum()))
+    term = float(p.kernel1) * float(mass.max()) * float(p.hscaled6)
+    drho = np.abs(part.mDensity.astype(np.float64) - ref["rho"].astype(np.float64))
+    lim = DENSITY_TERM_TOL * term + DENSITY_RTOL * np.abs(ref["rho"].astype(np.float64))
+    assert (drho <= lim).all(), "%s density off by %g of the largest term" % (what, (drho / term).max())
+    rel = vec_rel(part.mAcceleration, ref["acc"])
+    over = rel > FORCE_RTOL
+    if over.any():
+        assert scale is not None, "%s force rel err %g at %d particles" % (what, rel.max(), int(over.sum()))
+        err = np.linalg.norm(part.mAcceleration.astype(np.float64).reshape(-1, 3) -
+                             ref["acc"].astype(np.float64).reshape(-1, 3), axis=1)
+        cond = err[over] / scale()[over]
+        assert cond.max() <= FORCE_COND_TOL, "%s force error %g of the terms' magnitude sum (rel %g)" % (
+            what, cond.max(), rel.max())
+        assert over.mean() <= FORCE_COND_SHARE, "%s: %d particles beyond 1e-4 relative" % (what, int(over.sum()))
+    return rel.max(), (drho / term).max()
+
+
+def run_fast(oracle, p, pos, vel, mass, steps=1, mode=None):
+    """every step: the oracle starts from the state the GPU starts from"""
+    import smoothed_particle_hydrodynamics_amd as S
+    op = to_oracle_params(p)
+    edge = 1.0 / float(p.full_cell_inv)
+    worst = (0.0, 0.0)
+    with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST if mode is None else mode) as sph:
+        if mode is not None:
+            sph.setArithmetic(S.ARITH_FAST)
+        assert sph.getArithmetic() == S.ARITH_FAST
+        sph.setParticles(pos, vel, mass)
+        cur_pos, cur_vel = pos.copy(), vel.copy()
+        for s in range(steps):
+            sph.step()
+            part = sph.getParticles()
+            opos, ovel = cur_pos.copy(), cur_vel.copy()
+            ref = oracle.step(op, opos, ovel, mass, mode="full")
+            w = check_fast(part, ref, p, mass, "step %d" % s,
+                           scale=lambda: oracle.full_accel_scale(op, cur_pos, cur_vel, mass, ref["rho"]))
+            worst = (max(worst[0], w[0]), max(worst[1], w[1]))
+            assert vec_rel(part.mVelocity, ovel).max() <= FORCE_RTOL, "step %d velocity" % s
+            assert (np.abs(part.mPosition.astype(np.float64) - opos) <=
+                    1e-6 * edge + 2.0 ** -22 * np.abs(opos)).all(), "step %d position" % s
+            ke, pe = sph.energy()
+            assert ke == pytest.approx(ref["ke"], rel=1e-4, abs=1e-30)
+            cur_pos, cur_vel = part.mPosition.copy(), part.mVelocity.copy()
+    return worst
+
+
+def test_fast_dam_break_20k_10_steps(oracle, hiplib):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(20000, speed=0.05)
+    run_fast(oracle, p, pos, vel, mass, steps=10)
+
+
+def test_fast_dam_break_256k_moving(oracle, hiplib):
+    """BASELINE config C2, with a velocity field so that the viscous sum is live"""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(262144, speed=0.05)
+    run_fast(oracle, p, pos, vel, mass, steps=2)
+
+
+def test_fast_dense_block_with_point_mass_and_motion(oracle, hiplib):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(12000, speed=20.0)
+    run_fast(oracle, p, pos, vel, mass, steps=10)
+
+
+def test_fast_unequal_masses_and_scale(oracle, hiplib):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(6000, speed=5.0)
+    mass = (0.5 + scenes.uniform01(11, np.arange(mass.size))).astype(np.float32)
+    p.sim_scale = 0.5
+    p.sim_scale_inv = 2.0
+    run_fast(oracle, p, pos, vel, mass, steps=3)
+
+
+def test_fast_edge_cases(oracle, hiplib):
+    """duplicates (d = 0), particles outside the box, particles on cell faces, an over-full cell,
+    an isolated particle"""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(5000, lo=(-0.2, 0.0, 0.1), hi=(0.8, 0.6, 0.7), seed=5)
+    pos = pos.reshape(-1, 3)
+    pos[:50] = pos[50:100]
+    edge = np.float32(1.0) / np.float32(p.full_cell_inv)
+    pos[100:200] = edge * np.round(pos[100:200] / edge)
+    pos[200:210] = [9.0, -4.0, 3.0]
+    pos[210:700] = np.float32([3.31, 3.32, 3.33]) + np.float32(0.09) * (pos[210:700] % 1.0)
+    pos[700] = [5.5, 5.5, 5.5]
+    run_fast(oracle, p, np.ascontiguousarray(pos.reshape(-1)), vel, mass, steps=2)
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 257])
+def test_fast_tiny_counts(oracle, hiplib, n):
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(n, lo=(3.0, 3.0, 3.0), hi=(3.25, 3.25, 3.25))
+    run_fast(oracle, p, pos, vel, mass, steps=2)
+
+
+@pytest.mark.parametrize("env", [{"SPH_HIP_UNTILED": "1"}, {"SPH_HIP_TILE_CAP": "512"}, {"SPH_HIP_LIST_CAP": "30"}])
+def test_fast_every_route_same_bits(oracle, hiplib, env, monkeypatch):
+    """tiled, untiled, give-up workgroups, particles without a
+    list: the FAST arithmetic is written out operation by operation, so every route produces the
+    same bits as the default one - a slab's recomputed ghost densities equal their owner's"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(60000, speed=0.05)
+    out = []
+    for e in ({}, env):
+        for k in ("SPH_HIP_UNTILED", "SPH_HIP_TILE_CAP", "SPH_HIP_LIST_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST) as sph:
+            sph.setParticles(pos, vel, mass)
+            sph.run(2)
+            sph.step()
+            part = sph.getParticles()
+            out.append({k: getattr(part, k).copy() for k in ("mPosition", "mVelocity", "mDensity",
+                                                            "mAcceleration", "mNeighborCount")})
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
+def test_switching_arithmetic_on_a_live_context(oracle, hiplib):
+    """exact -> fast -> exact on one context: the exact steps are the oracle's bits again"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(30000, speed=0.05)
+    op = to_oracle_params(p)
+    with S.SPH(mass.size, p) as sph:
+        assert sph.getArithmetic() == S.ARITH_EXACT
+        sph.setParticles(pos, vel, mass)
+        sph.step()
+        sph.setArithmetic(S.ARITH_FAST)
+        sph.step()
+        sph.setArithmetic(S.ARITH_EXACT)
+        mid = sph.getParticles()
+        opos, ovel = mid.mPosition.copy(), mid.mVelocity.copy()
+        sph.step()
+        part = sph.getParticles()
+        ref = oracle.step(op, opos, ovel, mass, mode="full")
+        assert np.array_equal(part.mDensity, ref["rho"])
+        assert np.array_equal(part.mAcceleration, ref["acc"])
+        assert np.array_equal(part.mPosition, opos)
+
+
+def test_fast_is_refused_for_ref_mode(hiplib):
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(1000)
+    with S.SPH(mass.size, p, mode=S.MODE_REF) as sph:
+        with pytest.raises(S.SphHipError):
+            sph.setArithmetic(S.ARITH_FAST)

@@ -18,8 +18,9 @@ if len(sys.argv) > 1:
     sph.step(); sph.synchronize(); sph.setParticles(pos,vel,mass); sph.resetTimings()
     sph.step(); sph.synchronize()
     t,k=sph.phaseTotals()
-    print(os.path.basename(os.environ["SPH_HIP_LIBRARY"]), "density %.1f accel %.1f us"%(t[2]*1e3, t[4]*1e3), flush=True)
+    print(os.path.basename(os.environ["SPH_HIP_LIBRARY"]), os.environ.get("SPH_HIP_ARITH", "exact"), "density %.1f accel %.1f us"%(t[2]*1e3, t[4]*1e3), flush=True)
 else:
     for so in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build', 'variants', 'abl*.so'))):
         for r in range(2):
-            subprocess.run([sys.executable, __file__, "x"], env=dict(os.environ, SPH_HIP_LIBRARY=so), timeout=200)
+            subprocess.run([sys.executable, __file__, "x"],
+                           env=dict(os.environ, SPH_HIP_LIBRARY=so, SPH_HIP_ALLOW_DIAGNOSTIC="1"), timeout=200)

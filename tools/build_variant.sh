@@ -13,6 +13,10 @@ if [ "$rev" != "WORK" ]; then
    git -C "$root" archive "$rev" smoothed_particle_hydrodynamics_amd/csrc include | tar -x -C "$tmp"
    src="$tmp/smoothed_particle_hydrodynamics_amd/csrc"
 fi
-(cd "$src" && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -ldl "$@" \
+# (SPH_ABLATE hooks only compile in a declared diagnostic build, which the Python binding loads
+# only with SPH_HIP_ALLOW_DIAGNOSTIC=1: csrc/full_tiled.h)
+diag=""
+case " $* " in *SPH_ABLATE*) diag="-DSPH_DIAGNOSTIC_BUILD";; esac
+(cd "$src" && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -ldl $diag "$@" \
    -o "$root/build/variants/$name.so" sph_hip.hip)
 echo "built build/variants/$name.so from $rev $*"
