@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mparticle-steps/s of the SPH step on a synthetic dam-break.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 without WORLD_SIZE in the
+                                                            environment it starts the line below
+                                                            itself, as a child process)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 A "step" is one pass of the hot path (cell build + density + acceleration + integrate,
@@ -15,6 +17,7 @@ in `roofline` and `cpu_baseline`.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -65,7 +68,83 @@ def parse_args():
                     help="particles in the CPU-baseline sample (0 disables); with --cpu-steps "
                          "sized for ~10 s of single-thread work")
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--arithmetic", choices=("fast", "exact"), default="fast",
+                    help="pair arithmetic of the headline: fast = SPH_HIP_MODE_FULL_FAST (same "
+                         "neighbour sets and order, forces within the north star's 1e-4 of the CPU "
+                         "reference), exact = bit-identical to the CPU restatement; N = 1 reports "
+                         "the other one as a side record")
+    ap.add_argument("--no-preheat", action="store_true",
+                    help="N = 1: skip the 40 untimed steps on a scratch context right before the "
+                         "warm-up (after ANY idle period of 50 ms or more - an upload is one - "
+                         "the device needs ~15 steps to settle its clocks: tools/idle_ramp.py)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch rehearsal: start the ranks, form the process group, count them, "
+                         "print {\"dry_run\": true, \"ranks\": N}; no GPU work (checks a node's "
+                         "launch shape, and runs in the CPU test suite)")
+    ap.add_argument("--preflight-child", metavar="STORE", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks with
+    torch.distributed.run as a CHILD process and hand its exit code on.  This process never
+    touches the GPU (and never replaces itself: an exec from a process that has initialised the
+    GPU takes the machine down on this pool)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+PREFLIGHT_TIMEOUT_S = 240
+
+
+def preflight_child(args):
+    """Helper process of one rank (started by preflight() below, before that rank has touched
+    the GPU): bring RCCL up, exchange one small message with each neighbour, exit 0 if it arrived.
+    Anything else - an exception, a wrong byte, a hang that the parent's timeout ends - means the
+    ranks stage their halo messages through the host instead."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = 0 if os.environ.get("SPH_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    code = 3
+    try:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", init_method="file://" + args.preflight_child, rank=rank,
+                                world_size=world, timeout=datetime.timedelta(seconds=90),
+                                device_id=torch.device("cuda", local_rank))
+        if SL.neighbour_exchange_works(rank, world, "cuda", timeout_s=60.0):
+            code = 0
+    except Exception as exc:      # noqa: BLE001
+        print("pre-flight helper of rank %d: %r" % (rank, exc), file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    os._exit(code)                # no communicator teardown: it may be the thing that hangs
+
+
+def preflight(rank, world):
+    """Does the device-to-device neighbour exchange work on this node?  Asked of a helper process
+    per rank, with a time limit, BEFORE this process initialises the GPU or RCCL: a hang or a crash
+    in there is then a 'no', not a stuck or dead run."""
+    if os.environ.get("SPH_BENCH_FORCE_P2P_FALLBACK") == "1":
+        return False
+    store = "/tmp/sph_bench_preflight_%s_%s" % (os.environ.get("MASTER_PORT", "0"),
+                                                os.environ.get("TORCHELASTIC_RUN_ID", "run"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", store, "--gpus", str(world)]
+    try:
+        ok = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S).returncode == 0
+    except subprocess.TimeoutExpired:       # (subprocess.run has killed the child)
+        print("pre-flight helper of rank %d: no answer after %d s" % (rank, PREFLIGHT_TIMEOUT_S),
+              file=sys.stderr, flush=True)
+        ok = False
+    return ok
 
 
 def cpu_baseline(n_sample, steps, n_total):
@@ -150,12 +229,12 @@ def reference_scene(S, steps=8, n=32768):
     }
 
 
-PROFILE = os.path.join(ROOT, "profiles", "r2_kernel_counters.json")
+PROFILE = os.path.join(ROOT, "profiles", "r3_kernel_counters.json")
 
 
-def kernel_counters(n):
+def kernel_counters(n, arithmetic="fast"):
     """What the committed counter passes say about the density + acceleration launch pair
-    (tools/profile_round.sh -> profiles/r2_kernel_counters.json): HBM bytes (rocprofv3 --pmc
+    (tools/profile_round.sh -> profiles/r3_kernel_counters.json, one entry per arithmetic): HBM bytes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as the gfx950 guide prescribes) and
     VALU wave-instructions (SQ_INSTS_VALU).  The file carries the hash of the kernel sources it
     was measured on: (None, reason) when that is not the code being run, or the workload differs."""
@@ -166,10 +245,14 @@ def kernel_counters(n):
         return None, "no committed counter profile"
     if prof.get("particles") != n:
         return None, "the committed counters are for %s particles" % prof.get("particles")
+    if arithmetic not in prof.get("arithmetic", {}):
+        return None, "the committed counters do not cover the %s arithmetic" % arithmetic
     if prof.get("csrc_sha16") != source_hash():
         return None, ("the committed counters were taken on kernel sources %s, this is %s: "
                       "re-run tools/profile_round.sh" % (prof.get("csrc_sha16"), source_hash()))
-    return prof, "profiles/r2_kernel_counters.json (kernel sources %s)" % prof["csrc_sha16"]
+    out = dict(prof["arithmetic"][arithmetic], csrc_sha16=prof["csrc_sha16"])
+    return out, "profiles/%s, %s arithmetic (kernel sources %s)" % (
+        os.path.basename(PROFILE), arithmetic, prof["csrc_sha16"])
 
 
 def phase_split(ctx, S, step, synchronize, set_timing, phase_totals, steps=5):
@@ -194,39 +277,69 @@ def tile_summary(ts):
             "list_capacity": ts["list_capacity"]}
 
 
-def run_single(args, S, scenes, torch, local_rank):
-    """N = 1: one context holds the whole grid."""
-    n = args.particles
-    p, pos, vel, mass = scenes.dam_break(n)
-    sph = S.SPH(n, p, mode=S.MODE_FULL, device=local_rank)
-    sph.setParticles(pos, vel, mass)
-    # Timed region: HIP events (on the context's stream) bracket only the density+acceleration
-    # pair, and only on every PAIR_SAMPLE_EVERY-th step - each event record costs ~10 us of stream
-    # time; the full per-phase split is taken over a few extra steps after the timed region.
+def timed_steps(sph, S, torch, warmup, steps):
+    """`warmup` untimed steps, then exactly `steps` timed ones (device drained on both sides); the
+    density+acceleration pair is bracketed by HIP events on the context's stream on every
+    PAIR_SAMPLE_EVERY-th timed step only - an event record costs ~10 us of stream time."""
     sph.setTiming(S.TIMING_SUMS)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         sph.step()
     sph.synchronize()
     torch.cuda.synchronize()
     sph.setTimingStride(PAIR_SAMPLE_EVERY)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         sph.step()
     sph.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pair, covered = sph.phaseTotals()
     sph.setTimingStride(1)
+    return dt, pair[2] / covered, covered
+
+
+def run_single(args, S, scenes, torch, local_rank):
+    """N = 1: one context holds the whole grid."""
+    n = args.particles
+    fast = args.arithmetic == "fast"
+    p, pos, vel, mass = scenes.dam_break(n)
+    sph = S.SPH(n, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL, device=local_rank)
+    sph.setParticles(pos, vel, mass)
+    heater = None
+    if not args.no_preheat:
+        # Any idle period of >= 50 ms - the upload above is one - leaves the device ~15 steps away
+        # from its steady clocks (1.19, 1.27, 1.38, 1.37, 1.32 ... 1.06 ms per step, the same after
+        # a plain sleep: tools/idle_ramp.py): 40 untimed steps of the same workload on a scratch
+        # context, right before the warm-up, so that the timed region measures the step and not
+        # the power management's settling.
+        heater = S.SPH(n, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL, device=local_rank)
+        heater.setParticles(pos, vel, mass)
+        heater.setTiming(S.TIMING_OFF)
+        heater.run(40)
+        heater.synchronize()
+    dt, pair_ms, covered = timed_steps(sph, S, torch, args.warmup, args.steps)
     totals = phase_split(sph, S, lambda: sph.step(), sph.synchronize, sph.setTiming, sph.phaseTotals)
-    totals["pair_ms"] = pair[2] / covered
+    totals["pair_ms"] = pair_ms
     totals["tiles"] = tile_summary(sph.tileStats())
     nb_mean = float(sph.getParticles().mNeighborCount.mean())
     ke, pe = sph.energy()
     assert np.isfinite(ke) and np.isfinite(pe)
-    return p, dt, totals, covered, n, nb_mean, "1 GPU"
+    # the other arithmetic on the same context, same state, right behind (device still busy):
+    # a side record, never `value`
+    sph.setArithmetic(S.ARITH_EXACT if fast else S.ARITH_FAST)
+    odt, opair, ocovered = timed_steps(sph, S, torch, args.warmup, args.steps)
+    other = {"arithmetic": "exact" if fast else "fast", "value": n * args.steps / odt / 1e6,
+             "unit": "Mparticle-steps/s", "ms_per_step": odt / args.steps * 1e3,
+             "ms_per_launch_pair": opair, "launch_pairs_timed": ocovered,
+             "roofline_frac": DENSITY_FORCE_BYTES * n / (opair * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "note": "same context and state, %d warm-up + %d timed steps right behind the "
+                     "headline's; side record" % (args.warmup, args.steps)}
+    sph.close()
+    if heater is not None:
+        heater.close()
+    return p, dt, totals, covered, n, nb_mean, "1 GPU", other
 
 
-FALLBACK_GROUP = None               # gloo group of all ranks (N > 1): agreement channel + fallback transport
 C3_PARTICLES = 4 * 1024 * 1024      # BASELINE configs[2]
 C4_PARTICLES = 16 * 1024 * 1024     # BASELINE configs[3]: strong scaling over the node
 C5_PARTICLES = 64 * 1024 * 1024     # BASELINE configs[4]: 8:1:1 channel, long axis = slab axis
@@ -242,11 +355,12 @@ def config_name(n, box):
     return ""
 
 
-def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, warmup):
+def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, warmup, mode, exchange_group):
     """N > 1: `n` particles in `box`, one z-slab of the cell grid per GPU, neighbour exchange
     over RCCL (xGMI).  Every rank derives the same cuts from the z coordinates alone and
     generates only the particles it owns (counter-based PRNG: any subset of the scene on any
-    rank)."""
+    rank).  Everything that is not the halo exchange - barriers, the agreements about message size
+    and cuts, the max-over-ranks time - goes over the default gloo group with host tensors."""
     import torch.distributed as dist
     from smoothed_particle_hydrodynamics_amd import slab as SL
     p, hi = scenes.dam_break_params(n, box)
@@ -262,80 +376,73 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
         return SL.HipSlab(p, new_cuts[r], new_cuts[r + 1], c, max(m, msg), device=local_rank,
                           has_left=r > 0, has_right=r + 1 < world)
 
-    slab = SL.HipSlab(p, cuts[rank], cuts[rank + 1], cap, msg, device=local_rank,
-                      has_left=rank > 0, has_right=rank + 1 < world)
-    slab.upload(mine.astype(np.uint32), scenes.box_fill_subset(mine, (0.0, 0.0, 0.0), hi),
-                np.zeros(3 * mine.size, np.float32), np.ones(mine.size, np.float32),
-                all_masses_equal=True)
-    # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P);
-    # =native lets libsph_hip.so issue the RCCL calls itself (no Python in the step loop)
-    mode = os.environ.get("SPH_SLAB_TRANSPORT", "torch")
-    if mode == "torch" and FALLBACK_GROUP is not None:
-        # first contact with device-to-device P2P on this node: one small exchange with each
-        # neighbour; if any rank's fails, all ranks stage their messages through the host instead
-        # (agreed over gloo) and the JSON line says so - a slower number beats a crashed run
-        ok = SL.neighbour_exchange_works(rank, world, "cuda" if dist.get_backend() == "nccl" else "cpu")
-        if os.environ.get("SPH_BENCH_FORCE_P2P_FALLBACK") == "1":
-            ok = False
-        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=FALLBACK_GROUP)
-        if int(verdict.item()) == 0:
-            mode = "host-fallback"
+    first = SL.HipSlab(p, cuts[rank], cuts[rank + 1], cap, msg, device=local_rank,
+                       has_left=rank > 0, has_right=rank + 1 < world)
+    first.set_arithmetic(S.ARITH_FAST if args.arithmetic == "fast" else S.ARITH_EXACT)
+    first.set_timing(S.TIMING_SUMS)
+    first.upload(mine.astype(np.uint32), scenes.box_fill_subset(mine, (0.0, 0.0, 0.0), hi),
+                 np.zeros(3 * mine.size, np.float32), np.ones(mine.size, np.float32),
+                 all_masses_equal=True)
     if mode == "native":
-        stepper = SL.NativeSlabStepper(slab, rank, world)
+        stepper = SL.NativeSlabStepper(first, rank, world)
     else:
-        if mode == "host-fallback":
-            transport = SL.HostStagedTransport(rank, world, group=FALLBACK_GROUP)
+        if mode in ("host", "host-fallback"):
+            transport = SL.HostStagedTransport(rank, world)                 # default group: gloo
         else:
-            transport = (SL.HostStagedTransport if mode == "host" else SL.DistTransport)(rank, world)
+            transport = SL.DistTransport(rank, world, group=exchange_group)  # RCCL, P2P only
         # cuts are re-evaluated every 500 steps (a count per rank; particles move only when the
-        # fullest slab is 10 % over the mean), the message size every 256
-        stepper = SL.DistSlabStepper(slab, transport, make_slab=make_slab, cuts=cuts,
-                                     rebalance_every=500, imbalance=1.1, trim_every=256)
+        # fullest slab is 10 % over the mean), the message size every 256; a slab that replaces
+        # this one after a rebalance is stepper.slab - `first` is not used past this point
+        stepper = SL.DistSlabStepper(first, transport, make_slab=make_slab, cuts=cuts,
+                                     rebalance_every=500, imbalance=1.1, trim_every=256,
+                                     control_group=dist.group.WORLD)
+    del first
 
     def fence():
-        slab.synchronize()
+        stepper.slab.synchronize()
         torch.cuda.synchronize()
         dist.barrier()
 
-    slab.set_timing(S.TIMING_SUMS)
     for _ in range(warmup):
         stepper.step()
     fence()
     # from here on only the used part of the halo messages crosses the links (+25 % head room)
-    msg_records = stepper.trim_messages() if warmup > 0 else slab.msg_capacity
+    msg_records = stepper.trim_messages() if warmup > 0 else stepper.slab.msg_capacity
     fence()
-    slab.set_timing_stride(PAIR_SAMPLE_EVERY)
+    stepper.slab.set_timing_stride(PAIR_SAMPLE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         stepper.step()
     fence()
     dt_local = time.perf_counter() - t0
-    t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt_local], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    slab = stepper.slab
     st = slab.status()
-    flags = torch.tensor([st["errors"], st["owned"]], dtype=torch.int64, device="cuda")
-    err = flags[:1].clone()
+    err = torch.tensor([st["errors"]], dtype=torch.int64)
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
-    own = flags[1:].clone()
+    own = torch.tensor([st["owned"]], dtype=torch.int64)
     dist.all_reduce(own, op=dist.ReduceOp.SUM)
     if int(err.item()) != 0 or int(own.item()) != n:
         raise SystemExit("slab run inconsistent: error bits %d, owned %d of %d" %
                          (int(err.item()), int(own.item()), n))
     pair, covered = slab.phase_totals()
     slab.set_timing_stride(1)
-    totals = phase_split(slab, S, stepper.step, fence, slab.set_timing, slab.phase_totals)
-    totals["pair_ms"] = pair[2] / covered
+    totals = phase_split(slab, S, stepper.step, fence, lambda lv: stepper.slab.set_timing(lv),
+                         lambda: stepper.slab.phase_totals())
+    slab = stepper.slab
+    totals["pair_ms"] = pair[2] / max(covered, 1)
     totals["tiles"] = tile_summary(slab.tile_stats())
     d = slab.download()
     nb_mean = float(d["ncount"].mean())
+    msg_allocated = slab.msg_capacity
     slab.close()
     return {"params": p, "dt": dt, "totals": totals, "covered": covered, "n": n,
             "n_rank": st["owned"], "neighbors_mean": nb_mean, "steps": steps, "box": box,
             "ranks": dist.get_world_size(),
             "halo_message_bytes": SL.message_bytes(msg_records),
-            "halo_message_bytes_allocated": SL.message_bytes(slab.msg_capacity),
+            "halo_message_bytes_allocated": SL.message_bytes(msg_allocated),
             "parallelism": "z-slab x%d, RCCL halo (%s)" % (
                 world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so",
                         "host": "host-staged rehearsal",
@@ -344,11 +451,11 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
                             mode, "torch.distributed P2P"))}
 
 
-def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup):
+def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup, fast):
     """The same scene on ONE GPU in a single context (rank 0 only, the other ranks wait): the
     denominator of the strong-scaling speedup, measured in the same run on the same node."""
     p, pos, vel, mass = scenes.dam_break(n, box)
-    with S.SPH(n, p, mode=S.MODE_FULL, device=local_rank) as sph:
+    with S.SPH(n, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL, device=local_rank) as sph:
         sph.setParticles(pos, vel, mass)
         del pos, vel, mass
         sph.setTiming(S.TIMING_OFF)
@@ -361,7 +468,7 @@ def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup):
     return dt / steps * 1e3
 
 
-def breaking_dam(S, scenes, n, device, settle=500, timed=20):
+def breaking_dam(S, scenes, n, device, fast, settle=500, timed=20):
     """Side record, never `value`: the same scene with the dam actually breaking (uniform gravity
     and wall reflection switched on - SURVEY.md 8(f) rank 1), timed over steps settle ..
     settle + timed, when the column has collapsed and the flow is several times denser than the
@@ -371,7 +478,7 @@ def breaking_dam(S, scenes, n, device, settle=500, timed=20):
     p.apply_gravity = 1
     p.apply_walls = 1
     p.gravity[0], p.gravity[1], p.gravity[2] = 0.0, -9.81, 0.0
-    with S.SPH(n, p, mode=S.MODE_FULL, device=device) as sph:
+    with S.SPH(n, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL, device=device) as sph:
         sph.setParticles(pos, vel, mass)
         sph.setTiming(S.TIMING_OFF)
         sph.run(settle)
@@ -386,17 +493,20 @@ def breaking_dam(S, scenes, n, device, settle=500, timed=20):
                 n, settle, settle + timed),
             "ms_per_step": dt * 1e3, "value": n / dt / 1e6, "unit": "Mparticle-steps/s",
             "neighbors_mean": float(c.mean()), "neighbors_max": int(c.max()),
-            "particles_without_list": int((c > 254).sum()),
+            "list_capacity": int(ts["list_capacity"]),
+            "particles_without_list": int((c > ts["list_capacity"]).sum()),
             "workgroups_untiled": [int(ts["untiled_density"]), int(ts["untiled_acceleration"])],
             "note": "side record; `value` above is the column at rest, as in the reference"}
 
 
 def main():
     args = parse_args()
-    import torch
-    import smoothed_particle_hydrodynamics_amd as S
-    from smoothed_particle_hydrodynamics_amd import scenes
-
+    if args.preflight_child:
+        preflight_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the N = 1 bench is started: become the launcher (nothing has touched the
+        # GPU in this process, and nothing will)
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -405,6 +515,32 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+    import torch                      # (pages the image in before any helper process needs it)
+    if args.dry_run:
+        ranks = 1
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            ranks = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks": ranks}))
+        return
+    # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P);
+    # =native lets libsph_hip.so issue the RCCL calls itself (no Python in the step loop)
+    mode = os.environ.get("SPH_SLAB_TRANSPORT", "torch")
+    p2p_ok = True
+    if world > 1 and mode == "torch":
+        # first contact with device-to-device P2P on this node, in a helper process with a time
+        # limit, before this process initialises the GPU
+        p2p_ok = preflight(rank, world)
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+
     torch.cuda.set_device(local_rank)
     # The library is built in-tree by __graft_entry__.build(); only a missing one is compiled
     # here, and only when no other rank could be loading it at the same time.
@@ -414,18 +550,20 @@ def main():
                              "g; g.build()'` before a multi-rank launch")
         S.build_library()
     strong_scaling = None
+    other_arith = None
+    fast = args.arithmetic == "fast"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if (os.environ.get("SPH_SLAB_TRANSPORT") == "host" or
-                os.environ.get("SPH_BENCH_ONE_DEVICE") == "1"):   # rehearsals: ranks share a GPU
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        dist.barrier()
-        global FALLBACK_GROUP
-        FALLBACK_GROUP = dist.new_group(backend="gloo")
+        # The default group is gloo: barriers, reductions and every agreement between the ranks
+        # use host tensors and keep working whatever state the device-to-device path is in.  RCCL
+        # gets a group of its own that only the halo exchange uses.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        verdict = torch.tensor([1 if p2p_ok else 0], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        if mode == "torch" and int(verdict.item()) == 0:
+            mode = "host-fallback"     # all ranks alike; the JSON line says so
+        exchange_group = dist.new_group(backend="nccl") if mode == "torch" else None
         # strong (default): BASELINE configs[3] - 16M particles in the unit box cut in `world`
         # slabs; weak: `world` unit boxes in a row, --particles per GPU
         if args.scaling == "strong":
@@ -434,7 +572,8 @@ def main():
         else:
             n = (args.particles or C3_PARTICLES) * world
             box = (1.0, 1.0, float(world))
-        r = run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, args.steps, args.warmup)
+        r = run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, args.steps, args.warmup,
+                      mode, exchange_group)
         p, dt, totals, covered = r["params"], r["dt"], r["totals"], r["covered"]
         n_rank, nb_mean, par, ranks = r["n_rank"], r["neighbors_mean"], r["parallelism"], r["ranks"]
         halo = {"bytes_per_message": r["halo_message_bytes"],
@@ -444,7 +583,7 @@ def main():
             one_ms = None
             if rank == 0:
                 one_ms = one_gpu_reference(S, scenes, torch, local_rank, n, box,
-                                           max(5, args.steps // 2), min(args.warmup, 5))
+                                           max(5, args.steps // 2), min(args.warmup, 5), fast)
             dist.barrier()
             if rank == 0:
                 strong_scaling = {"particles": n, "one_gpu_ms_per_step": one_ms,
@@ -462,7 +601,7 @@ def main():
             else:
                 on, obox, oname = args.other_particles or C4_PARTICLES, (1.0, 1.0, 1.0), "strong"
             o = run_slabs(args, S, scenes, torch, rank, world, local_rank, on, obox,
-                          max(5, args.steps // 2), min(args.warmup, 3))
+                          max(5, args.steps // 2), min(args.warmup, 3), mode, exchange_group)
             other = {"scaling": oname, "particles": o["n"], "box": list(o["box"]),
                      "workload": "dam-break %d particles%s in a %gx%gx%g box" % (
                          o["n"], config_name(o["n"], obox), obox[0], obox[1], obox[2]),
@@ -472,15 +611,15 @@ def main():
     else:
         n = args.particles or C3_PARTICLES
         args.particles = n
-        p, dt, totals, covered, n_rank, nb_mean, par = run_single(args, S, scenes, torch,
-                                                                  local_rank)
+        p, dt, totals, covered, n_rank, nb_mean, par, other_arith = run_single(args, S, scenes, torch,
+                                                                               local_rank)
         box, other, ranks = (1.0, 1.0, 1.0), None, 1
 
     if rank == 0:
         # density+acceleration pair: HIP events on the context's stream over the timed steps
         df_ms = totals["pair_ms"]
         achieved = DENSITY_FORCE_BYTES * n_rank / (df_ms * 1e-3) / 1e9
-        prof, prof_note = kernel_counters(n) if world == 1 else (None, "1-GPU profile only")
+        prof, prof_note = kernel_counters(n, args.arithmetic) if world == 1 else (None, "1-GPU profile only")
         valu = None
         if prof is not None and prof.get("valu_wave_instructions_per_launch_pair"):
             # VALU issue: the SQ books one quad-cycle (4 cycles) of a SIMD per VALU wave-instruction
@@ -511,10 +650,14 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "dam-break %d particles%s in a %gx%gx%g box, fp32, FULL neighbour "
-                            "mode, cell grid rebuilt every step" % (
+                            "mode, cell grid rebuilt every step, %s" % (
                                 n, config_name(n, box) if world == 1 or scaling == "strong" else
                                 " = %d x %d, one unit box per slab along z" % (world, n // world),
-                                box[0], box[1], box[2]),
+                                box[0], box[1], box[2],
+                                "tolerance-mode pair arithmetic (SPH_HIP_MODE_FULL_FAST: neighbour sets "
+                                "and order identical to the CPU reference, forces within 1e-4 relative)"
+                                if fast else "pair arithmetic bit-identical to the CPU reference"),
+                "arithmetic": args.arithmetic,
                 "particles": n,
                 "particles_per_gpu": n // world,
                 "h": float(p.h),
@@ -559,8 +702,14 @@ def main():
             line["strong_scaling"] = strong_scaling
         if other is not None:
             line["other_scaling"] = other
+        if other_arith is not None:
+            line["other_arithmetic"] = other_arith
+        if world == 1 and not args.no_preheat:
+            line["config"]["preheat"] = ("40 untimed steps of the same workload on a scratch context "
+                                         "right before the warm-up (device clocks settle ~15 steps "
+                                         "after any idle period: tools/idle_ramp.py)")
         if world == 1 and not args.no_breaking_dam:
-            line["breaking_dam"] = breaking_dam(S, scenes, n, local_rank)
+            line["breaking_dam"] = breaking_dam(S, scenes, n, local_rank, fast)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
             ref_scene = reference_scene(S)

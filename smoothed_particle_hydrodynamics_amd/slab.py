@@ -88,6 +88,8 @@ class HipSlab:
         # records a message may hold right now (<= msg_capacity, what the buffers can take): what
         # the pack kernels enforce and what the transport moves - see trim_messages()
         self.msg_active = self.msg_capacity
+        self._settings = {}
+        self._counts_host = None
         self.device = torch.device("cuda", device)
         rc = self._lib.sph_hip_create_slab(C.byref(self._ctx), C.byref(self.params), self.capacity,
                                            int(device), self.plane_lo, self.plane_hi)
@@ -263,10 +265,51 @@ class HipSlab:
 
     def set_timing(self, level):
         self._check(self._lib.sph_hip_set_timing(self._ctx, int(level)), "sph_hip_set_timing")
+        self._settings["timing"] = int(level)
 
     def set_timing_stride(self, every):
         self._check(self._lib.sph_hip_set_timing_stride(self._ctx, int(every)),
                     "sph_hip_set_timing_stride")
+        self._settings["timing_stride"] = int(every)
+
+    def set_arithmetic(self, arithmetic):
+        """ARITH_EXACT / ARITH_FAST pair arithmetic (sph_hip_set_arithmetic); slabs start exact."""
+        self._check(self._lib.sph_hip_set_arithmetic(self._ctx, int(arithmetic)), "sph_hip_set_arithmetic")
+        self._settings["arithmetic"] = int(arithmetic)
+
+    def settings(self):
+        """What set_timing / set_timing_stride / set_arithmetic were last given: a slab that
+        replaces this one (DistSlabStepper.rebalance) is set up alike."""
+        return dict(self._settings)
+
+    def apply_settings(self, settings):
+        if "arithmetic" in settings:
+            self.set_arithmetic(settings["arithmetic"])
+        if "timing" in settings:
+            self.set_timing(settings["timing"])
+        if "timing_stride" in settings:
+            self.set_timing_stride(settings["timing_stride"])
+
+    def poll_send_counts(self):
+        """Records in the two messages, without draining the stream: returns what the copy
+        requested by the PREVIOUS call brought ((left, right), or None the first time) and
+        requests the next asynchronous copy of the two header words into pinned host memory."""
+        torch = self._torch
+        if self._counts_host is None:
+            self._counts_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._counts_event = torch.cuda.Event()
+            self._counts_pending = False
+        seen = None
+        if self._counts_pending:
+            self._counts_event.synchronize()          # requested one polling interval ago
+            seen = (int(self._counts_host[0]), int(self._counts_host[1]))
+        with torch.cuda.stream(self.stream):
+            for k, m in enumerate((self.send_left, self.send_right)):
+                if m is not None:
+                    self._counts_host[k:k + 1].copy_(m[:4].view(torch.int32), non_blocking=True)
+            self._counts_event.record(self.stream)
+        self._counts_pending = True
+        return seen
 
     def reset_timings(self):
         self._check(self._lib.sph_hip_reset_timings(self._ctx), "sph_hip_reset_timings")
@@ -340,11 +383,13 @@ class NativeSlabStepper:
         return self.slab.comm_trim(slack, extra)
 
 
-def neighbour_exchange_works(rank, world, device, group=None, nbytes=4096):
+def neighbour_exchange_works(rank, world, device, group=None, nbytes=4096, timeout_s=60.0):
     """Pre-flight of the slab exchange: one small batch_isend_irecv with each neighbouring rank on
-    `device` ("cuda" for RCCL, "cpu" for gloo), checked for content.  Returns this rank's verdict
-    (an exception counts as "no": the caller agrees on a fallback over a group that does not need
-    the path under test, bench.py).  Collective in the sense that every rank must call it."""
+    `device` ("cuda" for RCCL, "cpu" for gloo), checked for content.  Returns this rank's verdict:
+    an exception counts as "no", and so does an exchange that has not completed after `timeout_s`
+    (waited for by a helper thread: a transfer that hangs must not hang the caller, who then agrees on
+    a fallback over a group that does not need the path under test - bench.py runs this in a
+    helper process, so that a hung RCCL call can be left behind).  Every rank must call it."""
     import torch
     import torch.distributed as dist
     try:
@@ -357,11 +402,29 @@ def neighbour_exchange_works(rank, world, device, group=None, nbytes=4096):
         if rank + 1 < world:
             ops.append(dist.P2POp(dist.isend, mine, rank + 1, group))
             ops.append(dist.P2POp(dist.irecv, from_right, rank + 1, group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if str(device).startswith("cuda"):
-            torch.cuda.synchronize()
+        # the waiting is done by a helper thread: a transfer that never completes leaves that
+        # thread behind (daemon), not the caller
+        import threading
+        finished, failure = threading.Event(), []
+        on_device = str(device).startswith("cuda")
+
+        def wait_for_it():
+            try:
+                if on_device:
+                    torch.cuda.set_device(mine.device)
+                for req in (dist.batch_isend_irecv(ops) if ops else []):
+                    req.wait()
+                if on_device:
+                    torch.cuda.synchronize()
+            except Exception as exc:      # noqa: BLE001
+                failure.append(exc)
+            finished.set()
+
+        threading.Thread(target=wait_for_it, daemon=True).start()
+        if not finished.wait(timeout_s):
+            raise TimeoutError("no completion after %.0f s" % timeout_s)
+        if failure:
+            raise failure[0]
         ok = True
         if rank > 0:
             ok = ok and bool((from_left == (rank & 0xff)).all().item())
@@ -516,17 +579,24 @@ class DistSlabStepper:
     CHECK_EVERY = 16     # steps between two looks at the slab's error bits (no synchronisation)
 
     def __init__(self, slab, transport, overlap=True, make_slab=None, cuts=None,
-                 rebalance_every=0, imbalance=1.1, trim_every=0):
+                 rebalance_every=0, imbalance=1.1, trim_every=0, control_group=None):
         """make_slab(cuts, rank, plane_histogram) -> a new, empty slab for planes
         [cuts[rank], cuts[rank + 1]): needed for rebalance() (with `cuts`, the current ones).
         rebalance_every / trim_every: steps between collective re-evaluations of the cut planes
         (when the fullest slab holds more than `imbalance` x the mean) and of the message size
-        (0 = never; both synchronise the ranks, so hundreds of steps apart)."""
+        (0 = never; both synchronise the ranks, so hundreds of steps apart).
+        control_group: process group for everything that is NOT the halo exchange - the agreements
+        about message size and cut planes and the rows that change owner - with host tensors (a
+        gloo group: these must keep working where the device-to-device path does not; default:
+        the transport's own group, tensors where that group wants them)."""
         self.slab, self.transport = slab, transport
+        self.control_group = control_group
         self.overlap = overlap and hasattr(slab, "step_begin")
         self.make_slab, self.cuts = make_slab, (list(cuts) if cuts is not None else None)
         self.rebalance_every, self.imbalance, self.trim_every = rebalance_every, imbalance, trim_every
         self.rebalances = 0
+        self.message_growths = 0
+        self._trimmed = False           # trim_messages() has been used: all ranks poll from then on
         self._primed = False
         self._steps = 0
 
@@ -535,10 +605,13 @@ class DistSlabStepper:
             self.step()
 
     # ---- collectives between steps (every rank calls them at the same step) --------------------
+    def _group(self):
+        return self.control_group if self.control_group is not None else self.transport.group
+
     def _device(self):
-        """where this process group wants its tensors (RCCL: the slab's GPU; gloo: host)"""
+        """where the control group wants its tensors (RCCL: the slab's GPU; gloo: host)"""
         dist = self.transport.dist
-        backend = dist.get_backend(self.transport.group)
+        backend = dist.get_backend(self._group())
         return self.slab.device if backend == "nccl" and hasattr(self.slab, "device") else "cpu"
 
     def trim_messages(self, slack=1.25, extra=1024):
@@ -553,13 +626,38 @@ class DistSlabStepper:
         dist, slab = self.transport.dist, self.slab
         if not hasattr(slab, "send_counts"):
             return slab.msg_capacity
+        self._trimmed = True
         want = min(slab.msg_capacity, int(max(slab.send_counts()) * slack) + extra)
         t = torch.tensor([want], dtype=torch.int64, device=self._device())
         if self.transport.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.transport.group)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._group())
         slab.msg_active = int(t.item())
         self.transport.forget()
         return slab.msg_active
+
+    def grow_messages_if_needed(self, fill=0.8):
+        """A trimmed message must grow BEFORE it overflows (an overflow drops records: the run is
+        lost).  Called every CHECK_EVERY steps while the messages are trimmed: every rank looks at
+        the record counts an asynchronous copy brought since the last call (no synchronisation
+        with the device); when any rank's message is more than `fill` full, all of them go back to
+        the size the buffers were allocated for (the next trim_messages() tightens it again).
+        Collective over the control group (a few integers)."""
+        import torch
+        dist, slab = self.transport.dist, self.slab
+        if not hasattr(slab, "poll_send_counts") or self.transport.world == 1:
+            return False
+        if getattr(slab, "msg_active", slab.msg_capacity) >= slab.msg_capacity and not self._trimmed:
+            return False
+        seen = slab.poll_send_counts()
+        wish = 1 if (seen is not None and max(seen) > fill * slab.msg_active) else 0
+        t = torch.tensor([wish, -int(slab.msg_capacity)], dtype=torch.int64, device=self._device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._group())
+        if int(t[0].item()) == 0:
+            return False
+        slab.msg_active = min(slab.msg_capacity, -int(t[1].item()))   # what every rank's buffers hold
+        self.transport.forget()
+        self.message_growths += 1
+        return True
 
     def rebalance(self, force=False):
         """Re-evaluate the cut planes from the current distribution of the particles along z and
@@ -570,7 +668,7 @@ class DistSlabStepper:
         new slab): meant for every few hundred steps.  Returns True if the cuts changed."""
         import torch
         dist, tr, slab = self.transport.dist, self.transport, self.slab
-        rank, world, group = tr.rank, tr.world, tr.group
+        rank, world, group = tr.rank, tr.world, self._group()
         if world == 1 or self.make_slab is None or self.cuts is None:
             return False
         dev = self._device()
@@ -631,6 +729,9 @@ class DistSlabStepper:
         # the message size the ranks agreed on stays in force (all of them carry it over alike)
         new_slab.msg_active = min(getattr(slab, "msg_active", new_slab.msg_capacity),
                                   new_slab.msg_capacity)
+        # ... and so do the timing level, its stride and the pair arithmetic
+        if hasattr(slab, "settings") and hasattr(new_slab, "apply_settings"):
+            new_slab.apply_settings(slab.settings())
         if hasattr(slab, "close"):
             slab.close()
         self.slab, self.cuts = new_slab, list(new_cuts)
@@ -643,8 +744,11 @@ class DistSlabStepper:
         slab, tr = self.slab, self.transport
         # fail loudly: a run that has lost particles (message or capacity overflow, a particle the
         # early exchange missed) stops within 2 * CHECK_EVERY steps instead of running on
-        if self._steps % self.CHECK_EVERY == 0 and hasattr(slab, "poll_errors"):
-            slab.poll_errors()
+        if self._steps % self.CHECK_EVERY == 0:
+            if hasattr(slab, "poll_errors"):
+                slab.poll_errors()
+            if self._trimmed:
+                self.grow_messages_if_needed()
         if self._steps > 0:
             if self.rebalance_every and self._steps % self.rebalance_every == 0:
                 if self.rebalance():

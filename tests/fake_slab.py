@@ -25,6 +25,8 @@ class FakeSlab:
         self.ghosts = None
         self.last = None
         self.errors = 0
+        self._settings = {}
+        self._counts_seen = None
 
     def upload(self, ids, pos, vel, mass, all_masses_equal):
         self.all_masses_equal = bool(all_masses_equal)
@@ -134,6 +136,30 @@ class FakeSlab:
     def send_counts(self):
         return tuple(int(m.numpy()[:4].view(np.int32)[0]) if m is not None else 0
                      for m in (self.send_left, self.send_right))
+
+    def poll_send_counts(self):
+        """as HipSlab.poll_send_counts: what the previous call's request brought"""
+        seen, self._counts_seen = self._counts_seen, self.send_counts()
+        return seen
+
+    # what DistSlabStepper.rebalance carries over to the slab that replaces this one
+    def set_timing(self, level):
+        self._settings["timing"] = int(level)
+
+    def set_timing_stride(self, every):
+        self._settings["timing_stride"] = int(every)
+
+    def set_arithmetic(self, arithmetic):
+        self._settings["arithmetic"] = int(arithmetic)
+
+    def settings(self):
+        return dict(self._settings)
+
+    def apply_settings(self, settings):
+        self._settings.update(settings)
+
+    def close(self):
+        self.closed = True
 
     def status(self):
         return dict(live=0, owned=int(self.owned["ids"].size), errors=self.errors)

@@ -39,7 +39,8 @@ def test_counter_profile_is_only_used_for_the_code_it_was_taken_on(bench, tmp_pa
     from smoothed_particle_hydrodynamics_amd.build import source_hash
     n = 4 * 1024 * 1024
     good = {"particles": n, "csrc_sha16": source_hash(),
-            "density_plus_acceleration_hbm_bytes": 2.0e9, "valu_wave_instructions_per_launch_pair": 5.0e8}
+            "arithmetic": {"fast": {"density_plus_acceleration_hbm_bytes": 2.0e9,
+                                    "valu_wave_instructions_per_launch_pair": 5.0e8}}}
     path = tmp_path / "counters.json"
     monkeypatch.setattr(bench, "PROFILE", str(path))
     prof, why = bench.kernel_counters(n)                 # no file
@@ -47,6 +48,8 @@ def test_counter_profile_is_only_used_for_the_code_it_was_taken_on(bench, tmp_pa
     path.write_text(json.dumps(good))
     prof, why = bench.kernel_counters(n)
     assert prof["density_plus_acceleration_hbm_bytes"] == 2.0e9 and source_hash() in why
+    prof, why = bench.kernel_counters(n, "exact")        # counters of the other arithmetic only
+    assert prof is None and "exact" in why
     prof, why = bench.kernel_counters(n // 4)            # another workload
     assert prof is None and "particles" in why
     path.write_text(json.dumps(dict(good, csrc_sha16="0123456789abcdef")))
@@ -55,9 +58,64 @@ def test_counter_profile_is_only_used_for_the_code_it_was_taken_on(bench, tmp_pa
 
 
 def test_committed_counter_profile_matches_the_committed_kernels(bench):
-    """profiles/r2_kernel_counters.json must describe the kernel sources in this tree - otherwise
+    """profiles/r3_kernel_counters.json must describe the kernel sources in this tree - otherwise
     the driver's bench line silently loses roofline.traffic."""
-    prof, why = bench.kernel_counters(4 * 1024 * 1024)
-    assert prof is not None, why
-    assert 1.0e9 < prof["density_plus_acceleration_hbm_bytes"] < 4.0e9
-    assert 3.0e8 < prof["valu_wave_instructions_per_launch_pair"] < 1.0e9
+    for arithmetic in ("fast", "exact"):
+        prof, why = bench.kernel_counters(4 * 1024 * 1024, arithmetic)
+        assert prof is not None, why
+        assert 1.0e9 < prof["density_plus_acceleration_hbm_bytes"] < 4.0e9
+        assert 2.0e8 < prof["valu_wave_instructions_per_launch_pair"] < 1.0e9
+
+
+def test_gpus_n_without_world_size_becomes_the_launcher(bench, monkeypatch):
+    """`python bench.py --gpus 8` the way the driver starts the N = 1 bench: a child process running
+    torch.distributed.run on this very file with the same arguments, its exit code handed on - and
+    nothing in the parent that could touch a GPU before that."""
+    calls = []
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd: calls.append(cmd) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setitem(sys.modules, "torch", None)       # importing torch here would be a bug
+    with pytest.raises(SystemExit) as exit_info:
+        bench.main()
+    assert exit_info.value.code == 7
+    (cmd,) = calls
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_self_launched_ranks_print_one_line(tmp_path):
+    """end to end on CPU: bench.py --gpus 2 --dry-run starts two ranks through
+    torch.distributed.run (gloo), they count themselves, rank 0 prints ONE JSON line"""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    assert json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "ranks": 2}
+
+
+def test_control_plane_never_uses_the_exchange_group(bench, monkeypatch):
+    """bench.py's barriers and reductions go over the default (gloo) group with host tensors; RCCL
+    has a group of its own that only the transport is handed (a node whose
+    device-to-device path is broken must still get through the host-staged fallback)."""
+    import ast
+    import inspect
+    src = inspect.getsource(bench.run_slabs)
+    tree = ast.parse(src)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute):
+            if node.func.attr in ("all_reduce", "barrier", "all_gather", "broadcast"):
+                assert not any(kw.arg == "group" for kw in node.keywords), ast.dump(node)
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "tensor":
+            assert not any(kw.arg == "device" for kw in node.keywords), "control-plane tensors live on the host"
+    assert "exchange_group" in src and "control_group=dist.group.WORLD" in src
+    main_src = inspect.getsource(bench.main)
+    assert 'init_process_group("gloo"' in main_src and 'new_group(backend="nccl")' in main_src
+    assert main_src.index("preflight(rank, world)") < main_src.index("torch.cuda.set_device")

@@ -206,6 +206,95 @@ def test_cut_rebalancing_and_message_trimming_keep_the_bits(oracle, tmp_path, wo
     assert seen.all()
 
 
+def _worker_growth(rank, world, port, steps, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle
+        from fake_slab import FakeSlab
+        from smoothed_particle_hydrodynamics_amd.slab import (DistSlabStepper, DistTransport,
+                                                              plan_cuts, split_scene)
+        o = Oracle()
+        p = o.params_for_h(0.1)
+        pos, vel, mass = crowding_scene()
+        cuts = plan_cuts(p, pos.reshape(-1, 3)[:, 2], world)
+
+        def make_slab(new_cuts, r, hist):
+            return FakeSlab(o, p, new_cuts[r], new_cuts[r + 1], 8192, r > 0, r + 1 < world)
+
+        slab = make_slab(cuts, rank, None)
+        slab.set_timing(1)
+        slab.set_timing_stride(5)
+        slab.set_arithmetic(1)
+        slab.upload(*split_scene(p, cuts, rank, pos, vel, mass), all_masses_equal=False)
+        # the agreements travel over their own gloo group with host tensors (bench.py: the
+        # control plane must not depend on the device-to-device path)
+        control = dist.new_group(backend="gloo")
+        stepper = DistSlabStepper(slab, DistTransport(rank, world), overlap=True, make_slab=make_slab,
+                                  cuts=cuts, rebalance_every=0, control_group=control)
+        stepper.CHECK_EVERY = 2
+        active = []
+        for s in range(steps):
+            if s == 2:
+                stepper.trim_messages(slack=1.05, extra=4)      # tight on purpose
+            if s == steps - 2:
+                stepper.rebalance(force=True)
+            stepper.step()
+            active.append(stepper.slab.msg_active)
+        final = stepper.slab
+        assert final is not slab and getattr(slab, "closed", False)
+        assert final.settings() == {"timing": 1, "timing_stride": 5, "arithmetic": 1}
+        d = final.download()
+        assert final.status()["errors"] == 0
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), active=np.array(active),
+                 growths=stepper.message_growths, **d)
+    finally:
+        dist.destroy_process_group()
+
+
+def crowding_scene(n=6000):
+    """two blocks that run into each other across the middle of the z range: the strips next to
+    the cut fill up step by step - a trimmed message has to grow before it overflows"""
+    half = n // 2
+    lo = box_fill(half, (1.0, 1.0, 0.4), (2.0, 2.0, 1.5), 27).reshape(-1, 3)
+    hi = box_fill(n - half, (1.0, 1.0, 1.9), (2.0, 2.0, 3.0), 28).reshape(-1, 3)
+    pos = np.ascontiguousarray(np.concatenate([lo, hi]).reshape(-1))
+    vel = box_fill(n, (-5.0,) * 3, (5.0,) * 3, 29)
+    v = vel.reshape(-1, 3)
+    v[:half, 2] += np.float32(60.0)
+    v[half:, 2] -= np.float32(60.0)
+    mass = np.ones(n, np.float32)
+    return pos, vel, mass
+
+
+def test_trimmed_messages_grow_before_they_overflow_and_settings_survive_a_rebalance(oracle, tmp_path):
+    """Messages trimmed tightly while the strips next to the cut are still thin; then the blocks
+    meet there.  The ranks notice from asynchronously copied record counts (no device
+    synchronisation), agree over the control group and go back to the allocated size before
+    anything is dropped (FakeSlab asserts on an overflow); a forced rebalance late in the run
+    hands the timing level, stride and arithmetic on to the new slab, and the stepper's slab -
+    not the one the caller created - is the one that lives on."""
+    world, steps = 2, 12
+    port = _free_port()
+    mp.spawn(_worker_growth, args=(world, port, steps, str(tmp_path)), nprocs=world, join=True)
+    p = oracle.params_for_h(0.1)
+    pos, vel, mass = crowding_scene()
+    for _ in range(steps):
+        ref = oracle.step(p, pos, vel, mass, mode="full")
+    seen = np.zeros(mass.size, bool)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        ids = d["ids"].astype(np.int64)
+        seen[ids] = True
+        assert np.array_equal(d["pos"].reshape(-1, 3), pos.reshape(-1, 3)[ids])
+        assert np.array_equal(d["rho"], ref["rho"][ids])
+        assert int(d["growths"]) >= 1, "the crowding strips must have forced the messages to grow"
+        a = d["active"]
+        assert a[2] < 8192 and a[-1] == 8192, a
+    assert seen.all()
+
+
 def test_scene_subsets_match_the_whole_scene():
     """bench.py's ranks generate only their own slab: any coordinate axis or subset of rows of the
     counter-based scene must equal the corresponding part of the whole scene, and the parameters
