@@ -10,7 +10,10 @@ distributed run, only the transport differs (covered under gloo in test_slab_cpu
 The oracle cannot step these sizes, so parity is shown as in test_gpu_full_size.py:
   * 8 slabs == a single context, bit for bit, for every particle (SHA-256 of every array) -
     the single context being the configuration whose window is checked against the oracle;
-  * C4: an EXACT oracle check on the particles of a thin z-window that straddles a slab cut;
+  * C4: an EXACT oracle check on the particles of a thin z-window that straddles a slab cut - on
+    step 3 of a column that MOVES (seeded velocity field): with every particle at rest, as the
+    dam-break starts, v_j - v_i = 0 and the order-sensitive viscous sum of src/sph.cpp:875-882 is
+    identically zero in the comparison;
   * size-independent properties: every id owned exactly once, counts even (symmetric relation),
     ~32 neighbours, no error bit on any slab.
 """
@@ -58,14 +61,23 @@ def run_eight_slabs(p, pos, vel, mass, steps):
     return got, status, cuts
 
 
-def run_single(p, pos, vel, mass, steps):
+def run_single(p, pos, vel, mass, steps, keep_previous=False):
+    """keep_previous: also return positions and velocities as they were BEFORE the last step"""
     import smoothed_particle_hydrodynamics_amd as S
     with S.SPH(mass.size, p) as sph:
         sph.setParticles(pos, vel, mass)
-        sph.run(steps)
+        before = None
+        if keep_previous:
+            sph.run(steps - 1)
+            part = sph.getParticles()
+            before = (part.mPosition.copy(), part.mVelocity.copy())
+            sph.step()
+        else:
+            sph.run(steps)
         part = sph.getParticles()
-        return dict(pos=part.mPosition.copy(), vel=part.mVelocity.copy(), rho=part.mDensity.copy(),
-                    acc=part.mAcceleration.copy(), ncount=part.mNeighborCount.copy())
+        out = dict(pos=part.mPosition.copy(), vel=part.mVelocity.copy(), rho=part.mDensity.copy(),
+                   acc=part.mAcceleration.copy(), ncount=part.mNeighborCount.copy())
+        return (out, before) if keep_previous else out
 
 
 def check_properties(got, status, n):
@@ -79,14 +91,17 @@ def check_properties(got, status, n):
 
 def test_c4_eight_slabs_equal_single_context_and_oracle_window(oracle, hiplib):
     from smoothed_particle_hydrodynamics_amd import scenes
-    p, pos, vel, mass = scenes.dam_break(C4)
-    got, status, cuts = run_eight_slabs(p, pos, vel, mass, steps=1)
+    steps = 3
+    p, pos, vel, mass = scenes.dam_break(C4, speed=0.05)
+    got, status, cuts = run_eight_slabs(p, pos, vel, mass, steps=steps)
     check_properties(got, status, C4)
-    one = run_single(p, pos, vel, mass, steps=1)
+    one, (pos, vel) = run_single(p, pos, vel, mass, steps=steps, keep_previous=True)
     for k in ("pos", "vel", "rho", "acc", "ncount"):
         assert sha(got[k]) == sha(one[k]), k
-    # exact oracle check on a z-window around the cut between slabs 3 and 4: its particles and
-    # their neighbours (2h + margin) go to the oracle with the same parameters and grid
+    # exact oracle check of step 3 on a z-window around the cut between slabs 3 and 4: its
+    # particles and their neighbours (2h + margin) as they were after step 2 go to the oracle
+    # with the same parameters and grid
+    assert np.abs(vel).max() > 0.01
     h = np.float32(p.h)
     z = pos.reshape(-1, 3)[:, 2]
     cell = np.float32(1.0) / np.float32(p.full_cell_inv)

@@ -10,6 +10,10 @@ The oracle cannot step 4M particles in test time, so parity at this size is show
   * size-independent properties: every id downloaded exactly once, per-cell occupancy sums to N,
     the neighbour relation is symmetric (sum of counts even and equal to twice the pair count of
     the window), a second context with 2 slabs gives identical checksums.
+The window check is made twice: on step 1 of the column at rest (as the dam-break starts), and on
+step 3 of a column that moves (seeded velocity field), where v_j - v_i != 0 and the order-sensitive
+viscous sum of src/sph.cpp:875-882 - the reason for the canonical order - is live; the moving
+column is also stepped with the tolerance-mode arithmetic and held to that mode's bar.
 """
 import hashlib
 
@@ -73,6 +77,94 @@ def test_c3_window_matches_oracle_exactly(oracle, big_run):
     assert np.array_equal(r["pos"].reshape(-1, 3)[ids], spos.reshape(-1, 3)[inner])
     assert np.array_equal(r["vel"].reshape(-1, 3)[ids], svel.reshape(-1, 3)[inner])
     assert r["ncount"][ids].sum() > 1500000               # > 1.5M neighbour pairs checked exactly
+
+
+@pytest.fixture(scope="module")
+def moved_run(hiplib):
+    """3 steps of the moving column, exact and tolerance-mode arithmetic, with the state before
+    the last step"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(N, speed=0.05)
+    out = dict(p=p, mass=mass)
+    with S.SPH(N, p) as sph:
+        sph.setParticles(pos, vel, mass)
+        sph.run(2)
+        part = sph.getParticles()
+        out["pos0"], out["vel0"] = part.mPosition.copy(), part.mVelocity.copy()
+        sph.step()
+        part = sph.getParticles()
+        out["exact"] = dict(pos=part.mPosition.copy(), vel=part.mVelocity.copy(), rho=part.mDensity.copy(),
+                            acc=part.mAcceleration.copy(), ncount=part.mNeighborCount.copy())
+        # the same third step with the tolerance-mode arithmetic, from the same state
+        sph.setArithmetic(S.ARITH_FAST)
+        sph.setParticles(out["pos0"], out["vel0"], mass)
+        sph.step()
+        part = sph.getParticles()
+        out["fast"] = dict(pos=part.mPosition.copy(), vel=part.mVelocity.copy(), rho=part.mDensity.copy(),
+                           acc=part.mAcceleration.copy(), ncount=part.mNeighborCount.copy())
+    return out
+
+
+def oracle_window(oracle, r, z0, z1):
+    """the oracle's step on the particles within 2h (+ margin) of the z-window [z0, z1)"""
+    p = r["p"]
+    h = np.float32(p.h)
+    z = r["pos0"].reshape(-1, 3)[:, 2]
+    margin = np.float32(2.0) * h * np.float32(1.05) + np.float32(2.0) / np.float32(p.full_cell_inv)
+    sub = np.nonzero((z >= z0 - margin) & (z < z1 + margin))[0]          # ascending ids
+    inner = (z[sub] >= z0) & (z[sub] < z1)
+    assert inner.sum() > 50000 and sub.size < 600000
+    spos = np.ascontiguousarray(r["pos0"].reshape(-1, 3)[sub]).reshape(-1)
+    svel = np.ascontiguousarray(r["vel0"].reshape(-1, 3)[sub]).reshape(-1)
+    smass = np.ascontiguousarray(r["mass"][sub])
+    before = (spos.copy(), svel.copy())
+    ref = oracle.step(to_oracle_params(p), spos, svel, smass, mode="full")
+    return sub, inner, ref, spos, svel, smass, before
+
+
+def test_c3_moved_state_window_matches_oracle_exactly(oracle, moved_run):
+    """step 3 of the moving column: non-zero v_j - v_i in every viscous term"""
+    r, got = moved_run, moved_run["exact"]
+    assert np.abs(r["vel0"]).max() > 0.01
+    sub, inner, ref, spos, svel, _, _ = oracle_window(oracle, r, np.float32(0.400), np.float32(0.420))
+    ids = sub[inner]
+    assert np.array_equal(got["ncount"][ids], ref["ncount"][inner])
+    assert np.array_equal(got["rho"][ids], ref["rho"][inner])
+    assert np.array_equal(got["acc"].reshape(-1, 3)[ids], ref["acc"].reshape(-1, 3)[inner])
+    assert np.array_equal(got["pos"].reshape(-1, 3)[ids], spos.reshape(-1, 3)[inner])
+    assert np.array_equal(got["vel"].reshape(-1, 3)[ids], svel.reshape(-1, 3)[inner])
+    assert got["ncount"][ids].sum() > 1500000
+
+
+def test_c3_moved_state_window_tolerance_mode(oracle, moved_run):
+    """the same step with SPH_HIP_MODE_FULL_FAST's arithmetic, held to tests/test_gpu_full_fast.py's
+    bar on the window; neighbour counts identical over ALL 4M particles (against the exact mode,
+    whose window equals the oracle's)"""
+    from test_gpu_full_fast import check_fast
+    from helpers import vec_rel
+
+    class Part:
+        pass
+
+    r, got = moved_run, moved_run["fast"]
+    assert np.array_equal(got["ncount"], r["exact"]["ncount"])
+    sub, inner, ref, spos, svel, smass, before = oracle_window(oracle, r, np.float32(0.400), np.float32(0.420))
+    ids = sub[inner]
+    part = Part()
+    part.mNeighborCount = got["ncount"][ids]
+    part.mDensity = got["rho"][ids]
+    part.mAcceleration = np.ascontiguousarray(got["acc"].reshape(-1, 3)[ids]).reshape(-1)
+    wref = dict(ncount=ref["ncount"][inner], rho=ref["rho"][inner],
+                acc=np.ascontiguousarray(ref["acc"].reshape(-1, 3)[inner]).reshape(-1))
+    scale = lambda: oracle.full_accel_scale(to_oracle_params(r["p"]), before[0], before[1], smass, ref["rho"])[inner]
+    worst = check_fast(part, wref, r["p"], r["mass"], "C3 window", scale=scale)
+    assert vec_rel(got["vel"].reshape(-1, 3)[ids], svel.reshape(-1, 3)[inner]).max() <= 1e-4
+    # and over the whole scene against the exact mode (= the oracle wherever it was checked)
+    rel = vec_rel(got["acc"], r["exact"]["acc"])
+    assert (rel > 1e-4).mean() <= 1e-4, "%d of %d particles beyond 1e-4" % ((rel > 1e-4).sum(), rel.size)
+    print("C3 window, tolerance mode: max force rel err %.3g, max density err %.3g of a term; whole scene vs "
+          "exact mode: max %.3g, %d beyond 1e-4" % (worst[0], worst[1], rel.max(), (rel > 1e-4).sum()))
 
 
 def test_c3_two_slabs_identical(big_run):
