@@ -25,6 +25,7 @@
 
 #include "common_kernels.h"
 #include "full_kernels.h"
+#include "slab_kernels.h"
 
 // SPH_ABLATE=N cuts a piece out of a kernel so that tools/ablate.py can price it: such a build
 // computes garbage.  It only compiles as a declared diagnostic build (tools/build_variant.sh adds
@@ -375,8 +376,12 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                      int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
                      uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
                      int tile_cap, int32_t* __restrict__ tile_stats,
-                     const uint32_t* __restrict__ giveup, int* __restrict__ tile_feedback, int list_cap)
+                     const uint32_t* __restrict__ giveup, int* __restrict__ tile_feedback, int list_cap,
+                     double* __restrict__ epart_clear)
 {
+   // A slab whose acceleration pass integrates (FusedStep) writes one pair of energy partial sums
+   // per workgroup that owns particles; the others' must read zero whatever an earlier step left
+   if (epart_clear && threadIdx.x < 2) epart_clear[2 * blockIdx.x + threadIdx.x] = 0.0;
    __shared__ TileDesc sd;
    __shared__ int list_overflow;
    TileLds L;
@@ -692,8 +697,9 @@ __device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairC
 {
    double ke = 0.0, pe = 0.0;
    uint32_t c = 0xffffffffu;
+   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
    if (live) {
-      float4 v = fs.velp_in[p];
+      v = fs.velp_in[p];
       integrate_particle<UNIT_SCALE>(k, x, v, a, ke, pe);
       fs.posm_out[p] = x;
       fs.velp_out[p] = v;
@@ -702,6 +708,50 @@ __device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairC
       fs.key[p] = c;
    }
    count_cell_runs(c, live, p, fs.cell_count, fs.slot, (uint32_t)g.ncells);
+   if (fs.slab) {
+      // the halo messages, by the particle's NEW plane exactly as k_slab_pack_early classifies:
+      // particles of the owned planes next to a neighbouring slab (sorted ranges
+      // [OWN_BEGIN, BND_LO_END) and [BND_HI_BEGIN, OWN_END)) go into that neighbour's message when
+      // they are within the halo of its territory or beyond; a particle further inside that ended
+      // up there moved more than a cell plane in one step - nobody has it as a ghost: say so
+      bool to_left = false, to_right = false;
+      if (live) {
+         const int ob = fs.meta[META_OWN_BEGIN], oe = fs.meta[META_OWN_END];
+         const int lo_end = min(fs.meta[META_BND_LO_END], oe);
+         const int hi_begin = min(max(fs.meta[META_BND_HI_BEGIN], lo_end), oe);
+         const int plane = cell_coord(x.z, g.inv, g.nz_global);
+         const bool near_left = fs.zone.have_left && plane < fs.zone.lo + fs.zone.halo;
+         const bool near_right = fs.zone.have_right && plane >= fs.zone.hi - fs.zone.halo;
+         if ((p >= ob && p < lo_end) || (p >= hi_begin && p < oe)) {
+            to_left = near_left;
+            to_right = near_right;
+         } else if (near_left || near_right) {
+            atomicOr(&fs.meta[META_ERRORS], 8);
+         }
+      }
+      if (fs.zone.have_left) {
+         const int s = msg_reserve(&fs.left->header[0], to_left);
+         if (to_left) {
+            if (s < fs.msg_capacity) {
+               fs.left->rec[2 * s] = x;
+               fs.left->rec[2 * s + 1] = v;
+            } else {
+               atomicOr(&fs.meta[META_ERRORS], 2);
+            }
+         }
+      }
+      if (fs.zone.have_right) {
+         const int s = msg_reserve(&fs.right->header[0], to_right);
+         if (to_right) {
+            if (s < fs.msg_capacity) {
+               fs.right->rec[2 * s] = x;
+               fs.right->rec[2 * s + 1] = v;
+            } else {
+               atomicOr(&fs.meta[META_ERRORS], 2);
+            }
+         }
+      }
+   }
    // block reduction, fixed order (the same as k_integrate's: same partial sums)
    __shared__ double s_ke[TILE_THREADS / SPH_WAVE], s_pe[TILE_THREADS / SPH_WAVE];
 #pragma unroll
@@ -754,7 +804,13 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    const int wg = mapped < 0 ? 0 : mapped;
    const int p0 = begin + wg * TILE_THREADS;
    // (the density pass has finished: what it counted goes to the host's pinned copy)
-   if (blockIdx.x == 0 && tid == 0) tile_feedback[TSTAT_NO_LIST] = tile_stats[TSTAT_NO_LIST];
+   if (blockIdx.x == 0 && tid == 0) {
+      tile_feedback[TSTAT_NO_LIST] = tile_stats[TSTAT_NO_LIST];
+      if (fs.slab && part == 1) {   // the border part packs the messages: the size they are packed for
+         if (fs.left) fs.left->header[1] = fs.msg_capacity;
+         if (fs.right) fs.right->header[1] = fs.msg_capacity;
+      }
+   }
    // nothing of its own to do for workgroups past the range or made of ghosts only - nor, when
    // the pass is launched in two parts (early exchange), for those of the other part
    const bool own = mapped >= 0 && !(p0 >= end || p0 + TILE_THREADS <= ob || p0 >= oe) &&

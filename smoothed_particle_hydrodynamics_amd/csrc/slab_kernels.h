@@ -159,6 +159,40 @@ k_slab_pack_early(const float4* __restrict__ posm, const float4* __restrict__ ve
    }
 }
 
+// Cell build of a slab whose last step was integrated and hashed by its acceleration pass
+// (FusedStep): key, slot and the cells' counts of the owned entries of the previous sorted order
+// [OWN_BEGIN, OWN_END) are already there.  What is left: that order's other entries - last step's
+// ghosts, re-sent by their owner every step - go to the trash cell, and the records received since
+// (entries [N_LIVE, N_IN)) are hashed and counted like k_hash_count does.  Grid-stride over the
+// entries outside the owned range.
+__global__ void __launch_bounds__(256)
+k_hash_tail(const float4* __restrict__ posm, int32_t* __restrict__ meta, CellGrid g,
+            uint32_t* __restrict__ key, uint32_t* __restrict__ slot, uint32_t* __restrict__ cell_count)
+{
+   const int ob = meta[META_OWN_BEGIN], oe = meta[META_OWN_END];
+   const int n_live = meta[META_N_LIVE], n_in = meta[META_N_IN];
+   const int todo = ob + (n_in - oe);
+   // (whole waves stay in the loop together: count_cell_runs is a wave-wide operation)
+   for (int q0 = blockIdx.x * blockDim.x; q0 < todo; q0 += gridDim.x * blockDim.x) {
+      const int q = q0 + threadIdx.x;
+      const bool live = q < todo;
+      const int i = q < ob ? q : oe + (q - ob);
+      uint32_t c = 0xffffffffu;
+      if (live) {
+         if (i < n_live) {
+            c = (uint32_t)g.ncells;          // last step's ghost
+         } else {
+            const float4 p = posm[i];
+            int cx, cy, cz;
+            c = cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+            if (c == (uint32_t)g.ncells) atomicOr(&meta[META_ERRORS], 1);   // received, but not ours to hold
+         }
+         key[i] = c;
+      }
+      count_cell_runs(c, live, i, cell_count, slot, (uint32_t)g.ncells);
+   }
+}
+
 // Appends the records of the received messages behind the live entries [0, n_live) and sets
 // n_in, the entry count of the next cell build.  One launch for both messages.
 __global__ void __launch_bounds__(256)

@@ -83,6 +83,7 @@ enum {
 // computed - into the state buffers the cell build left free, the neighbours still read the old
 // ones - and hashed and counted for the next cell build; no k_integrate launch, no second trip of
 // positions, velocities and accelerations through HBM.
+struct SlabMsg;
 struct FusedStep {
    int on;
    const float4* velp_in;   // velocity + id of the state the sums read
@@ -92,6 +93,17 @@ struct FusedStep {
    uint32_t* key;           // next build: cell id, slot inside the cell, the cells' counts
    uint32_t* slot;
    uint32_t* cell_count;
+   // A slab that exchanges early (sph_hip_slab_step_begin / _end): the two parts of the
+   // acceleration launch do the rest of the step for the particles they own - integrate, hash for
+   // the next build, and, in the border part, the halo messages (what k_slab_pack_early did from
+   // a second read of the state).  The next build only has to hash what arrives from the
+   // neighbours (k_hash_tail).
+   int slab;
+   SlabZone zone;
+   SlabMsg* left;
+   SlabMsg* right;
+   int msg_capacity;
+   int32_t* meta;           // error bits
 };
 struct TileCaps {
    int cand[TILE_CANDS];    // ascending candidate capacities (the occupancy levels of both kernels)
@@ -170,6 +182,10 @@ struct sph_hip_context {
    int uniform_mass = 0;           // every resident particle has bit-identical mass
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
    int prehashed = 0;              // the last integrate also did the next build's cell hash + counts
+                                   // (2: a slab's fused step - owned entries only, see k_hash_tail)
+   int slab_fused = 0;             // the step in progress (step_begin .. step_end) is fused
+   void* slab_msgs[2] = {nullptr, nullptr};   // its message buffers
+   int slab_msg_capacity = 0;
    int had_exchange = 0;           // pack/unpack/step_begin were used on this context: never prehash
    int may_hold_dead = 0;          // sph_hip_slab_pack has marked entries dead since the last cell build
    int early_exchange = 0;         // the last step packed its messages early (sph_hip_slab_step_begin)

@@ -383,7 +383,13 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    hipStream_t st = ctx->stream;
    const int cur = ctx->cur;
    const SlabZone zone = slab_zone(ctx);
-   if (ctx->prehashed) {
+   if (ctx->prehashed == 2) {
+      // a slab whose last step was integrated and hashed by its acceleration pass: only last
+      // step's ghosts (to the trash cell) and the records received since are left
+      ctx->prehashed = 0;
+      hipLaunchKernelGGL(k_hash_tail, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, st, ctx->posm[cur], ctx->meta, g,
+                         ctx->key, ctx->slot, ctx->cell_count);
+   } else if (ctx->prehashed) {
       ctx->prehashed = 0;   // the last integrate hashed and counted this very state already
    } else if (ctx->mode == SPH_HIP_MODE_REF)
       hipLaunchKernelGGL((k_hash_count<true, false>), dim3(blocks), dim3(256), 0, st, ctx->posm[cur],
@@ -488,22 +494,34 @@ int launch_find_neighbors(sph_hip_context* ctx)
    return SPH_HIP_OK;
 }
 
+// message buffers of a slab whose acceleration pass does the rest of the step (FusedStep.slab)
+struct SlabFused {
+   void* left;
+   void* right;
+   int capacity;
+};
+
 // tiled kernels of the two sums, specialised on (unit simulation scale, uniform mass)
 void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k)
 {
    const int cap = ctx->caps.cap_density;
    const size_t lds = (size_t)(cap + TILE_PAD) * DENSITY_TILE_BYTES;
+   // (a slab: the fused acceleration pass writes energy partials only for workgroups that own
+   // particles; this launch zeroes the others' - same grid, one pair per workgroup)
+   const bool whole = ctx->plane_lo == 0 && ctx->plane_hi == ctx->grid.nz_global;
+   double* epart_clear = whole ? nullptr : ctx->epart + 2;
    bind_flags([&](auto U, auto M, auto W, auto F) {
       hipLaunchKernelGGL((k_full_density_tiled<U.value, M.value, W.value, F.value>), dim3(blocks),
                          dim3(TILE_THREADS), lds, ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur],
                          ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc,
                          ctx->ncount, ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap,
-                         ctx->tile_stats, ctx->giveup_density, ctx->tile_feedback, ctx->list_cap);
+                         ctx->tile_stats, ctx->giveup_density, ctx->tile_feedback, ctx->list_cap,
+                         epart_clear);
    }, unit, ctx->uniform_mass != 0, ctx->caps.wide != 0, ctx->fast != 0);
 }
 
 void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part,
-                        hipStream_t st, bool fused = false)
+                        hipStream_t st, bool fused = false, const SlabFused* slab = nullptr)
 {
    FusedStep fs;
    memset(&fs, 0, sizeof(fs));
@@ -516,6 +534,14 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
       fs.key = ctx->key;
       fs.slot = ctx->slot;
       fs.cell_count = ctx->cell_count;
+      if (slab) {
+         fs.slab = 1;
+         fs.zone = slab_zone(ctx);
+         fs.left = (SlabMsg*)slab->left;
+         fs.right = (SlabMsg*)slab->right;
+         fs.msg_capacity = slab->capacity;
+         fs.meta = ctx->meta;
+      }
    }
    const int cap = ctx->caps.cap_accel;
    const size_t lds = (size_t)(cap + TILE_PAD) * ACCEL_TILE_BYTES;
@@ -557,7 +583,8 @@ int launch_density(sph_hip_context* ctx)
 
 // part: 0 = all workgroups; 1 / 2 = those with / without particles of the owned planes next to
 // a neighbouring slab (early exchange; tiled FULL mode only)
-int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = nullptr, bool fused = false)
+int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = nullptr, bool fused = false,
+                 const SlabFused* slab = nullptr)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
@@ -571,7 +598,7 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
       const bool unit = unit_scale(ctx->prm);
       if (ctx->use_tiled) {
          // same tiling (and tile descriptors) as the density pass of this step
-         launch_accel_lists(ctx, unit, div_up(n, TILE_THREADS), k, part, part ? part_stream : ctx->stream, fused);
+         launch_accel_lists(ctx, unit, div_up(n, TILE_THREADS), k, part, part ? part_stream : ctx->stream, fused, slab);
       } else {
          bind_flags([&](auto U, auto F) {
             hipLaunchKernelGGL((k_full_accel<U.value, F.value>), dim3(blocks), dim3(256), 0, ctx->stream,
@@ -1420,7 +1447,9 @@ int sph_hip_slab_unpack(sph_hip_context* ctx, const void* left_device, const voi
    if (rc) return rc;
    if (ctx->mode != SPH_HIP_MODE_FULL || capacity_records < 0) return SPH_HIP_ERR_INVALID;
    ctx->had_exchange = 1;
-   if ((rc = drop_prehash(ctx))) return rc;
+   // (a slab's fused step has hashed its owned entries for the next build, which hashes what is
+   // unpacked here: that stays; a whole-grid prehash knows nothing of new entries)
+   if (ctx->prehashed != 2 && (rc = drop_prehash(ctx))) return rc;
    // entries behind the live ones; n_in = n_live + what the messages hold
    hipLaunchKernelGGL(k_slab_unpack, dim3(div_up(2 * capacity_records, 256) + 1), dim3(256), 0,
                       ctx->stream, (const SlabMsg*)left_device, (const SlabMsg*)right_device,
@@ -1446,7 +1475,7 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
       return SPH_HIP_ERR_INVALID;
    }
    ctx->had_exchange = 1;
-   if ((rc = drop_prehash(ctx))) return rc;
+   if (ctx->prehashed != 2 && (rc = drop_prehash(ctx))) return rc;
    hipStream_t st = ctx->stream;
    hipStream_t side = exchange_stream ? (hipStream_t)exchange_stream : st;
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
@@ -1465,6 +1494,20 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
    if (side != st) {
       SPH_TRY(hipEventRecord(ctx->ev_density, st));
       SPH_TRY(hipStreamWaitEvent(side, ctx->ev_density, 0));
+   }
+   // The two parts of the acceleration launch do the rest of the step themselves (FusedStep):
+   // integrate into the other pair of state buffers, hash for the next build, and - the border
+   // part - the messages.  SPH_HIP_NO_FUSED_SLAB=1 keeps k_slab_pack_early + k_integrate.
+   ctx->slab_fused = getenv_flag("SPH_HIP_NO_FUSED_SLAB") ? 0 : 1;
+   ctx->slab_msgs[0] = left_device;
+   ctx->slab_msgs[1] = right_device;
+   ctx->slab_msg_capacity = capacity_records;
+   if (ctx->slab_fused) {
+      const SlabFused sf = {left_device, right_device, capacity_records};
+      if ((rc = launch_accel(ctx, 1, side, true, &sf))) return rc;
+      if (side != st) SPH_TRY(hipEventRecord(ctx->ev_border, side));
+      ctx->border_stream = side;
+      return SPH_HIP_OK;
    }
    if ((rc = launch_accel(ctx, 1, side))) return rc;
    const PairConsts k = pair_consts(ctx->prm);
@@ -1495,6 +1538,19 @@ int sph_hip_slab_step_end(sph_hip_context* ctx)
    hipEvent_t* ev = ctx->ev + 7 * (ctx->ev_steps % EV_RING);
    const int level = ctx->slab_step_level;
    const bool phases = level == SPH_HIP_TIMING_PHASES, sums = level == SPH_HIP_TIMING_SUMS;
+   if (ctx->slab_fused && ctx->n > 0) {
+      const SlabFused sf = {ctx->slab_msgs[0], ctx->slab_msgs[1], ctx->slab_msg_capacity};
+      if ((rc = launch_accel(ctx, 2, st, true, &sf))) return rc;
+      if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
+      // what follows on this stream (unpack, the next build) reads what the border part wrote
+      if (ctx->border_stream != st) SPH_TRY(hipStreamWaitEvent(st, ctx->ev_border, 0));
+      ctx->cur ^= 1;                                    // the new state is in the other buffers
+      ctx->energy_blocks = div_up(ctx->n, TILE_THREADS);
+      ctx->prehashed = 2;
+      if (phases) SPH_TRY(hipEventRecord(ev[6], st));
+      if (level != SPH_HIP_TIMING_OFF) ctx->ev_steps++;
+      return SPH_HIP_OK;
+   }
    if ((rc = launch_accel(ctx, 2, st))) return rc;
    if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
    // the integrate needs the border planes' acceleration (and must not move them under the pack)
