@@ -35,6 +35,40 @@ def means(pattern, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
+VALU_CLASSES = ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_ADD_F64",
+                "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+                "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"]
+
+
+def arithmetic_of(kernel):
+    """the tiled pair kernels carry the FAST flag as their last template argument"""
+    if "<" not in kernel:
+        return None
+    args = [a.strip() for a in kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")]
+    return "fast" if args[-1] == "true" else "exact"
+
+
+def ubench_calibration(out, tag):
+    """per microbenchmark kernel (k<MODE>): class counters per SQ_INSTS_VALU - how the SQ counts
+    each instruction form (a packed fp32 op as one FMA_F32? cmp/cndmask under INT32?)"""
+    names = ["fma_f32", "mul_f32", "add_f32", "pk_fma_f32", "pk_add_f32", "pk_mul_f32", "add_u32", "and_b32",
+             "lshl_or_b32", "bfe_u32", "alignbit_b32", "ffbl_b32", "cmp+cndmask", "rcp_f32", "rsq_f32", "sqrt_f32",
+             "fma_f64", "mul_f64", "add_f64", "rcp_f64", "mov_b32", "fma_f32+alignbit"]
+    table = {}
+    for sub in ("_ubench_pmc1", "_ubench_pmc2"):
+        pattern = os.path.join(out, tag + sub, "**", "*counter_collection.csv")
+        total = means(pattern, "SQ_INSTS_VALU")
+        for counter in VALU_CLASSES:
+            vals = means(pattern, counter)
+            for k, (v, _) in vals.items():
+                if not k.startswith("k<") or k not in total or total[k][0] == 0:
+                    continue
+                mode = int(k[2:k.index(">")])
+                table.setdefault(names[mode] if mode < len(names) else k, {})[counter] = round(v / total[k][0], 4)
+    return table
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
     out = "gpurun_out"
@@ -42,6 +76,11 @@ def main():
     write = means(os.path.join(out, tag + "_pmc_write", "**", "*counter_collection.csv"), "WRITE_SIZE")
     valu = means(os.path.join(out, tag + "_pmc_valu", "**", "*counter_collection.csv"), "SQ_INSTS_VALU")
     waves = means(os.path.join(out, tag + "_pmc_valu", "**", "*counter_collection.csv"), "SQ_WAVES")
+    classes = {}
+    for sub in ("_pmc_valu", "_pmc_valu2"):
+        for counter in VALU_CLASSES:
+            for k, (v, _) in means(os.path.join(out, tag + sub, "**", "*counter_collection.csv"), counter).items():
+                classes.setdefault(k, {})[counter] = v
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from smoothed_particle_hydrodynamics_amd.build import source_hash
     kernels = {}
@@ -53,23 +92,32 @@ def main():
         if k in valu:
             kernels[k]["SQ_INSTS_VALU"] = valu[k][0]
             kernels[k]["SQ_WAVES"] = waves.get(k, (0.0, 0))[0]
+        kernels[k].update(classes.get(k, {}))
     doc = {
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU SQ_WAVES "
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU + class counters "
                   "(separate passes), python3 bench.py --steps 4 --warmup 1 --cpu-sample 0 "
-                  "--no-breaking-dam, 4194304-particle dam-break, MI355X (tools/profile_round.sh)",
+                  "--no-breaking-dam --no-preheat (both pair arithmetics per run), 4194304-particle "
+                  "dam-break, MI355X (tools/profile_round.sh)",
         "csrc_sha16": source_hash(),
         "units": "counter values are KiB per dispatch (mean over dispatches); hbm_bytes = "
                  "(2*FETCH_SIZE + WRITE_SIZE)*1024 - FETCH_SIZE doubled as MI355X_MICROARCH.md "
                  "prescribes for 16-B/lane streaming reads on gfx950",
         "particles": int(os.environ.get("SPH_PROFILE_PARTICLES", 4 * 1024 * 1024)),
-        "density_plus_acceleration_hbm_bytes": sum(
-            v["hbm_bytes"] for k, v in kernels.items()
-            if k.startswith("k_full_density") or k.startswith("k_full_accel")),
-        "valu_wave_instructions_per_launch_pair": sum(
-            v.get("SQ_INSTS_VALU", 0.0) for k, v in kernels.items()
-            if k.startswith("k_full_density") or k.startswith("k_full_accel")),
+        "arithmetic": {},
+        "ubench_counter_calibration": ubench_calibration(out, tag),
         "kernels": kernels,
     }
+    for arith in ("fast", "exact"):
+        pair = {k: v for k, v in kernels.items()
+                if (k.startswith("k_full_density") or k.startswith("k_full_accel")) and arithmetic_of(k) == arith}
+        if not pair:
+            continue
+        entry = {"kernels": sorted(pair),
+                 "density_plus_acceleration_hbm_bytes": sum(v["hbm_bytes"] for v in pair.values()),
+                 "valu_wave_instructions_per_launch_pair": sum(v.get("SQ_INSTS_VALU", 0.0) for v in pair.values())}
+        for counter in VALU_CLASSES:
+            entry[counter] = sum(v.get(counter, 0.0) for v in pair.values())
+        doc["arithmetic"][arith] = entry
     path = os.path.join(out, tag + "_kernel_counters.json")
     with open(path, "w") as fh:
         json.dump(doc, fh, indent=1)
