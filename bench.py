@@ -255,6 +255,62 @@ def kernel_counters(n, arithmetic="fast"):
         os.path.basename(PROFILE), arithmetic, prof["csrc_sha16"])
 
 
+PRICES = os.path.join(ROOT, "profiles", "r3_valu_prices.json")
+
+
+def valu_issue(prof, pair_ms):
+    """What share of the SIMDs' cycles the pair's VALU instructions book - the bound that is real
+    for this pass.  Three figures:
+      flat4  every VALU wave-instruction at 4 cycles: the SQ's own accounting (SQ_ACTIVE_INST_VALU
+             books one quad-cycle for a 2- and a 4-cycle instruction alike, two for a
+             transcendental, four for v_rcp_f64: profiles/r3_kernel_counters.json,
+             ubench_counter_calibration) - round 2's figure;
+      low / high  the counted classes at the prices tools/ubench/valu3.hip measured with every SIMD
+             saturated (profiles/r3_valu_prices.json, cycles at the clock the chip held): plain
+             fp32 / int32 adds, multiplies, fused multiply-adds and moves 2.24 - MI355X_MICROARCH.md
+             says 2; the difference is the loop's own scalar instructions - packed fp32,
+             v_alignbit / v_bfe / v_lshl_or / v_ffbl / v_cmp / v_cndmask and fp64 4.1-4.3,
+             transcendentals 8.1, v_rcp_f64 16.2.  The class counters do not tell a packed fp32
+             operation from a plain one, nor the 4-cycle integer forms from the 2-cycle ones (same
+             calibration): `low` prices every such instruction at the plain rate, `high` at the wide
+             one; the truth lies between (TEST's distance arithmetic is packed, the pair arithmetic
+             is not)."""
+    insts = prof.get("valu_wave_instructions_per_launch_pair")
+    if not insts:
+        return None
+    try:
+        table = json.load(open(PRICES))["instructions"]
+        price = lambda name: table[name]["cycles"][3]          # 8 waves per SIMD
+        plain = (price("v_fma_f32") + price("v_add_f32") + price("v_add_u32")) / 3.0
+        wide = (price("v_pk_fma_f32") + price("v_alignbit_b32") + price("v_cmp + v_cndmask")) / 3.0
+        trans, f64, rcp64 = price("v_rcp_f32"), price("v_fma_f64"), price("v_rcp_f64")
+        ghz = sorted(table[n]["ghz"][3] for n in table)
+        # the clock the pair kernels themselves held in the counter pass (GRBM_GUI_ACTIVE / 8 / the
+        # dispatch's duration), else the median of the microbenchmark's runs
+        clock = prof.get("shader_clock_ghz_while_profiled") or ghz[len(ghz) // 2]
+    except (OSError, KeyError, ValueError):
+        return {"wave_instructions_per_launch_pair": insts, "note": "no price table (profiles/r3_valu_prices.json)"}
+    cls = lambda name: prof.get("SQ_INSTS_VALU_" + name, 0.0)
+    f32 = cls("ADD_F32") + cls("MUL_F32") + cls("FMA_F32")
+    f64n = cls("ADD_F64") + cls("MUL_F64") + cls("FMA_F64") + cls("INT64")
+    other = insts - f32 - f64n - cls("TRANS_F32") - cls("TRANS_F64")     # int32, cvt, moves, logic, selects
+    fixed = cls("TRANS_F32") * trans + cls("TRANS_F64") * rcp64 + f64n * f64
+    simd_cycles = 1024.0 * pair_ms * 1e-3 * clock * 1e9
+    return {"wave_instructions_per_launch_pair": insts,
+            "classes": {"fp32_add_mul_fma": f32, "fp64_and_int64": f64n, "trans_f32": cls("TRANS_F32"),
+                        "trans_f64": cls("TRANS_F64"), "int32_moves_logic_selects": other},
+            "cycles_per_wave_instruction": {"plain": plain, "wide": wide, "trans_f32": trans, "fp64": f64,
+                                            "rcp_f64": rcp64},
+            "simds": 1024, "clock_ghz": clock,
+            "frac_low": ((f32 + other) * plain + fixed) / simd_cycles,
+            "frac_high": ((f32 + other) * wide + fixed) / simd_cycles,
+            "frac_flat4": insts * 4.0 / simd_cycles,
+            "note": "share of the SIMDs' issue cycles the pair's VALU instructions book, at the clock "
+                    "the pair kernels held in the counter pass (GRBM_GUI_ACTIVE): low / high = the "
+                    "instructions the counters cannot classify as plain or wide at either price; "
+                    "flat4 = the SQ's own accounting (round 2's figure).  See valu_issue() in bench.py"}
+
+
 def phase_split(ctx, S, step, synchronize, set_timing, phase_totals, steps=5):
     """Per-phase milliseconds over `steps` fully instrumented steps (outside the timed region)."""
     set_timing(S.TIMING_PHASES)
@@ -620,17 +676,7 @@ def main():
         df_ms = totals["pair_ms"]
         achieved = DENSITY_FORCE_BYTES * n_rank / (df_ms * 1e-3) / 1e9
         prof, prof_note = kernel_counters(n, args.arithmetic) if world == 1 else (None, "1-GPU profile only")
-        valu = None
-        if prof is not None and prof.get("valu_wave_instructions_per_launch_pair"):
-            # VALU issue: the SQ books one quad-cycle (4 cycles) of a SIMD per VALU wave-instruction
-            # (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in the committed passes); the chip has
-            # 256 CUs x 4 SIMDs; elapsed = the pair's live duration at the nominal 2.4 GHz
-            insts = prof["valu_wave_instructions_per_launch_pair"]
-            valu = {"wave_instructions_per_launch_pair": insts, "cycles_per_wave_instruction": 4,
-                    "simds": 1024, "clock_ghz": 2.4,
-                    "frac": insts * 4.0 / (1024 * df_ms * 1e-3 * 2.4e9),
-                    "note": "share of the SIMDs' issue cycles the pair's VALU instructions book: "
-                            "this is the bound that is real for the pass (DESIGN.md 3.2)"}
+        valu = valu_issue(prof, df_ms) if prof is not None else None
         scaling = args.scaling if world > 1 else "weak"
         line = {
             "metric": "Mparticle-steps/sec (whole node), dam-break" + (

@@ -35,6 +35,22 @@ def means(pattern, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
+def clocks(pattern):
+    """shader clock a kernel ran at, GHz: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the
+    dispatch's duration (MI355X_MICROARCH.md, DVFS give-back); reads high on dispatches shorter
+    than ~0.3 ms"""
+    acc = {}
+    for path in glob.glob(pattern, recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != "GRBM_GUI_ACTIVE":
+                    continue
+                s = acc.setdefault(short(row["Kernel_Name"]), [0.0, 0.0])
+                s[0] += float(row["Counter_Value"]) / 8.0
+                s[1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    return {k: v[0] / v[1] for k, v in acc.items() if v[1] > 0}
+
+
 VALU_CLASSES = ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
                 "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_ADD_F64",
                 "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
@@ -81,6 +97,7 @@ def main():
         for counter in VALU_CLASSES:
             for k, (v, _) in means(os.path.join(out, tag + sub, "**", "*counter_collection.csv"), counter).items():
                 classes.setdefault(k, {})[counter] = v
+    ghz = clocks(os.path.join(out, tag + "_pmc_valu2", "**", "*counter_collection.csv"))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from smoothed_particle_hydrodynamics_amd.build import source_hash
     kernels = {}
@@ -93,6 +110,8 @@ def main():
             kernels[k]["SQ_INSTS_VALU"] = valu[k][0]
             kernels[k]["SQ_WAVES"] = waves.get(k, (0.0, 0))[0]
         kernels[k].update(classes.get(k, {}))
+        if k in ghz:
+            kernels[k]["shader_clock_ghz_while_profiled"] = ghz[k]
     doc = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU + class counters "
                   "(separate passes), python3 bench.py --steps 4 --warmup 1 --cpu-sample 0 "
@@ -117,6 +136,9 @@ def main():
                  "valu_wave_instructions_per_launch_pair": sum(v.get("SQ_INSTS_VALU", 0.0) for v in pair.values())}
         for counter in VALU_CLASSES:
             entry[counter] = sum(v.get(counter, 0.0) for v in pair.values())
+        cl = [v["shader_clock_ghz_while_profiled"] for v in pair.values() if "shader_clock_ghz_while_profiled" in v]
+        if cl:
+            entry["shader_clock_ghz_while_profiled"] = sum(cl) / len(cl)
         doc["arithmetic"][arith] = entry
     path = os.path.join(out, tag + "_kernel_counters.json")
     with open(path, "w") as fh:

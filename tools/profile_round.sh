@@ -22,7 +22,7 @@ pargs="bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-breaking-dam --no-prehe
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python3 $pargs > $out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python3 $pargs > $out/${tag}_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --output-format csv -d $out/${tag}_pmc_valu -o run -- python3 $pargs > $out/${tag}_pmc_valu.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/${tag}_pmc_valu2 -o run -- python3 $pargs > $out/${tag}_pmc_valu2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_valu2 -o run -- python3 $pargs > $out/${tag}_pmc_valu2.log 2>&1
 # how the counters count the microbenchmark's instruction classes (calibration of the class mapping)
 if [ -x build/ubench/valu3 ]; then
    ./build/ubench/valu3 $out/${tag}_valu_prices.json > $out/${tag}_valu_prices.txt
