@@ -82,8 +82,10 @@ __device__ __forceinline__ void density_untiled(int p, const float4* __restrict_
    rho[p] = density;
    const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
    const float4 v = velp[p];
-   velB[p] = make_float4(v.x, v.y, v.z, bc.x);
-   auxc[p] = bc.y;
+   // (FAST: the two factors change places - {v, C} is what only the viscous sum's last few
+   // neighbours need, m B what every pair needs: see visc_keep)
+   velB[p] = make_float4(v.x, v.y, v.z, FAST ? bc.y : bc.x);
+   auxc[p] = FAST ? bc.x : bc.y;
    ncount[p] = count;
 }
 
@@ -107,7 +109,8 @@ __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ 
                                               const float* __restrict__ auxc,
                                               const uint32_t* __restrict__ cell_start,
                                               const CellGrid& g, const PairConsts& k,
-                                              float4* __restrict__ acc)
+                                              float4* __restrict__ acc,
+                                              const int32_t* __restrict__ ncount = nullptr)
 {
    const float4 pi = posm[p];
    int cx, cy, cz;
@@ -117,6 +120,12 @@ __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ 
 
    AccelState s;
    accel_begin(k, s, pi, velB[p], rho[p]);
+   // FAST: the viscous sum visits the last visc_keep() neighbours only (ncount from the density pass)
+   int first_v = 0, j = 0;
+   if (FAST) {
+      const int cnt = ncount[p], keep = visc_keep(s.visc_scale);
+      first_v = keep < cnt ? cnt - keep : 0;
+   }
 #pragma unroll 1
    for (int row = 0; row < 9; row++) {
       const uint32_t b = row == 0 ? r.s[0] : row == 1 ? r.s[1] : row == 2 ? r.s[2] : row == 3 ? r.s[3]
@@ -129,13 +138,19 @@ __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ 
          float dx, dy, dz;
          const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
          if (d2 < k.h2) {
-            const float4 vj = velB[q];
             float d = sqrtf(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
-            if (FAST)
-               accel_pair_fast<UNIT_SCALE>(k, s, dx, dy, dz, d, vj.x, vj.y, vj.z, vj.w, auxc[q]);
-            else
+            if (FAST) {
+               const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, auxc[q]);
+               if (j >= first_v) {
+                  const float4 vj = velB[q];
+                  accel_pair_fast_viscous(s, hd, vj.x, vj.y, vj.z, vj.w);
+               }
+               j++;
+            } else {
+               const float4 vj = velB[q];
                accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w, vj.x, vj.y, vj.z, vj.w, auxc[q]);
+            }
          }
       }
    }
@@ -147,11 +162,11 @@ __global__ void __launch_bounds__(256)
 k_full_accel(const float4* __restrict__ posm, const float4* __restrict__ velB,
              const float* __restrict__ rho, const float* __restrict__ auxc,
              const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta, CellGrid g,
-             PairConsts k, float4* __restrict__ acc)
+             PairConsts k, float4* __restrict__ acc, const int32_t* __restrict__ ncount)
 {
    // same workgroup -> particle mapping as the tiled kernels (from the density range); the
    // acceleration is only needed for owned particles
    const int p = meta[META_SUM_BEGIN] + blockIdx.x * blockDim.x + threadIdx.x;
    if (p < meta[META_OWN_BEGIN] || p >= meta[META_OWN_END]) return;
-   accel_untiled<UNIT_SCALE, FAST>(p, posm, velB, rho, auxc, cell_start, g, k, acc);
+   accel_untiled<UNIT_SCALE, FAST>(p, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
 }

@@ -629,8 +629,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       rho_out[p] = density;
       const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
       const float4 v = velp[p];
-      velB_out[p] = make_float4(v.x, v.y, v.z, bc.x);  // what the acceleration pass gathers
-      auxc_out[p] = bc.y;                              // ... and what it stages in its tile
+      // what the acceleration pass gathers, and what it stages in its tile (FAST: the two factors
+      // change places - only the viscous sum's last few neighbours are gathered: visc_keep)
+      velB_out[p] = make_float4(v.x, v.y, v.z, FAST ? bc.y : bc.x);
+      auxc_out[p] = FAST ? bc.x : bc.y;
       ncount[p] = count;
    }
 }
@@ -824,7 +826,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
       const int gp = g0 + tid;
       const bool mine = gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta);
-      if (mine) accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc);
+      if (mine) accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
       if (fs.on) {
          float4 gx = make_float4(0.f, 0.f, 0.f, 0.f), ga = gx;
          if (mine) {
@@ -893,7 +895,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          for (int kk = 1; kk < 9; kk++) d = (idx >= B[kk]) ? D[kk] : d;
          buf[r] = posm[idx - d];
          cbuf[r] = auxc[idx - d];
-         }
+      }
 #pragma unroll
       for (int r = 0; r < BATCH; r++) {
          const int idx = base + tid + r * TILE_THREADS;
@@ -911,6 +913,13 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // skips the list loop and walks its candidate ranges in the tile afterwards
    bool no_list = false;
    if (gave_up == 2u && cnt > 0) no_list = my_list[0] == NLIST_NO_LIST;
+   // FAST: only the last visc_keep() neighbours take part in the viscous sum - and only they are
+   // gathered ({v, C}; what every pair needs, m B, is in the tile)
+   int first_v = 0;
+   if (FAST) {
+      const int keep = visc_keep(s.visc_scale);
+      first_v = keep < cnt ? cnt - keep : 0;
+   }
    if (no_list) cnt = 0;
 #if defined(SPH_ABLATE) && SPH_ABLATE == 21
    cnt = 0;   // timing only: prologue and epilogue
@@ -929,15 +938,23 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
-         const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
-         const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
-#if defined(SPH_ABLATE) && SPH_ABLATE == 7
-         vj[u] = make_float4(1.f, 2.f, 3.f, 4.f);  // timing only: no gather
-#else
-         vj[u] = velB[qq];
-#endif
          mj[u] = pi.w;
-         if (!UNIFORM_MASS && !FAST) mj[u] = posm[qq].w;   // (FAST: the mass rides in B)
+         if (FAST) {
+            vj[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 + u >= first_v && j0 + u < cnt) {   // (lanes that skip it cost the texture path nothing)
+               const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
+               vj[u] = velB[q];
+            }
+         } else {
+            const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
+            const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
+#if defined(SPH_ABLATE) && SPH_ABLATE == 7
+            vj[u] = make_float4(1.f, 2.f, 3.f, 4.f);  // timing only: no gather
+#else
+            vj[u] = velB[qq];
+#endif
+            if (!UNIFORM_MASS) mj[u] = posm[qq].w;
+         }
       }
       // the next trip's list entries travel while this trip's pairs are computed
 #pragma unroll
@@ -956,11 +973,13 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #if defined(SPH_ABLATE) && SPH_ABLATE == 22
             s.pgx += d + vj[u].x + pj.w;   // timing only: no pair arithmetic
 #else
-            if (FAST)
-               accel_pair_fast<UNIT_SCALE>(k, s, dx, dy, dz, d, vj[u].x, vj[u].y, vj[u].z, vj[u].w, pj.w);
-            else
+            if (FAST) {
+               const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
+               if (j0 + u >= first_v) accel_pair_fast_viscous(s, hd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
+            } else {
                accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
                                       pj.w, in_range);
+            }
 #endif
          }
       }
@@ -972,6 +991,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
       row_ranges(g, cell_start, cx, cy, cz, rr);
       const int self_t = p + L.desc.D[4];
+      int jw = 0;   // neighbours visited so far (FAST: first_v was taken from the full count above)
 #pragma unroll
       for (int kk = 0; kk < 9; kk++) {
          const int D = L.desc.D[kk];
@@ -981,12 +1001,17 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
             if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
-               const float4 vj = velB[t - D];
                float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                if (FAST) {
-                  accel_pair_fast<UNIT_SCALE>(k, s, dx, dy, dz, d, vj.x, vj.y, vj.z, vj.w, pj.w);
+                  const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
+                  if (jw >= first_v) {
+                     const float4 vj = velB[t - D];
+                     accel_pair_fast_viscous(s, hd, vj.x, vj.y, vj.z, vj.w);
+                  }
+                  jw++;
                } else {
+                  const float4 vj = velB[t - D];
                   float mj = pi.w;
                   if (!UNIFORM_MASS) mj = posm[t - D].w;
                   accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj, vj.x, vj.y, vj.z, vj.w, pj.w, in_range);

@@ -171,11 +171,10 @@ __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, f
 // is a relative error of ulp * h / (h - d) in the whole term - measured 1.5e-3 on accelerations
 // with a hardware square root on the fused d2.
 // Bm = m_j * B: the density pass of a FAST context stores the product (neighbor_terms_fast), so no
-// route of the acceleration pass gathers masses.
+// route of the acceleration pass gathers masses.  Returns h - d for the viscous part.
 template <bool UNIT_SCALE>
-__device__ __forceinline__ void accel_pair_fast(const PairConsts& k, AccelState& s, float dx, float dy,
-                                                float dz, float d, float vjx, float vjy, float vjz,
-                                                float Bm, float C)
+__device__ __forceinline__ float accel_pair_fast_pressure(const PairConsts& k, AccelState& s, float dx,
+                                                          float dy, float dz, float d, float Bm)
 {
    const float rden = __builtin_amdgcn_rcpf(d + 0.01f);
    const float hd = k.hscaled - d;
@@ -184,11 +183,36 @@ __device__ __forceinline__ void accel_pair_fast(const PairConsts& k, AccelState&
    s.pgx = __builtin_fmaf(dx, f, s.pgx);
    s.pgy = __builtin_fmaf(dy, f, s.pgy);
    s.pgz = __builtin_fmaf(dz, f, s.pgz);
-   // viscosity, rescaled inside the neighbour loop (:880-882)
+   return hd;
+}
+
+// viscosity, rescaled inside the neighbour loop (:880-882)
+__device__ __forceinline__ void accel_pair_fast_viscous(AccelState& s, float hd, float vjx, float vjy,
+                                                        float vjz, float C)
+{
    const float c2 = hd * C;
    s.vtx = __builtin_fmaf(vjx - s.vx, c2, s.vtx) * s.visc_scale;
    s.vty = __builtin_fmaf(vjy - s.vy, c2, s.vty) * s.visc_scale;
    s.vtz = __builtin_fmaf(vjz - s.vz, c2, s.vtz) * s.visc_scale;
+}
+
+// How many of a particle's LAST neighbours the viscous sum of a FAST context has to visit.  The
+// reference rescales the running sum by s = mu * rhoiInv after every neighbour (:880-882), so the
+// neighbour that is m-th from the end enters with the weight s^m: with the reference's constants
+// |s| is of the order 1e-7 in a fluid under pressure and 1e-2 (= mu) where the pressure is not
+// positive, and all but the last few terms are below anything fp32 resolves.  A term is left out
+// when its weight is below 1e-20 (2^-66.4): the last ceil(66.4 / -log2 |s|) neighbours are kept, all
+// of them when |s| >= 1/2.  What is left out is at most 1e-20 of the largest viscous term of the
+// particle - against a tolerance of 1e-4 on the acceleration - and the neighbours that are left
+// out need neither their velocity nor their C: the only per-neighbour gather of the acceleration
+// pass shrinks from ~31 to ~4 per particle (it was the pass's floor: DESIGN.md 3.2).
+__device__ __forceinline__ int visc_keep(float visc_scale)
+{
+   const float a = __builtin_fabsf(visc_scale);
+   if (!(a < 0.5f)) return 0x7fffffff;            // (NaN too)
+   if (a < 1.0e-30f) return 1;
+   const float m = __builtin_ceilf(66.4386f / -__builtin_amdgcn_logf(a));
+   return m < 1.0f ? 1 : (int)m;
 }
 
 // reference src/sph.cpp:888-933

@@ -172,7 +172,7 @@ struct sph_hip_context {
    // sums
    float* rho = nullptr;
    float4* velB = nullptr; // per particle {vx, vy, vz, B = p_j * rhojInv^2}: the acceleration gather
-   float* auxc = nullptr;  // per particle C = (rhojInv * m_j) * k3: staged in the acceleration tile
+   float* auxc = nullptr;  // per particle C = (rhojInv * m_j) * k3 (FAST: m_j * B): staged in the acceleration tile
    float4* acc = nullptr; // {ax, ay, az, unused}
    int32_t* ncount = nullptr;
    struct TileDesc* tile_desc = nullptr; // per 256-particle workgroup: LDS tile layout

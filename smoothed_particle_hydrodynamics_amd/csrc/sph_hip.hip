@@ -603,7 +603,7 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
          bind_flags([&](auto U, auto F) {
             hipLaunchKernelGGL((k_full_accel<U.value, F.value>), dim3(blocks), dim3(256), 0, ctx->stream,
                                ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc, ctx->cell_start,
-                               ctx->meta, ctx->grid, k, ctx->acc);
+                               ctx->meta, ctx->grid, k, ctx->acc, ctx->ncount);
          }, unit, ctx->fast != 0);
       }
    }
