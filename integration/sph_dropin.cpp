@@ -53,7 +53,8 @@ int g_mode = SPH_HIP_MODE_REF;    // SPH_HIP_MODE_FULL for complete neighbourhoo
 // The two host mirrors: `front` is what getParticles() hands out, `back` is being filled by the
 // library (or waits to be).  Both are the reference's own `Particle` (std::vector storage,
 // page-locked once so that the copy into it is a DMA the solver thread does not wait for).
-Particle* g_back = nullptr;
+Particle* g_back = nullptr;      // being filled by the copy stream
+Particle* g_retired = nullptr;   // the front of one swap ago: a GUI frame may still be reading it
 std::vector<int32_t> g_counts_front, g_counts_back;   // per-voxel occupancy on the reference grid
 bool g_copy_in_flight = false;
 bool g_sync_mirror = false;       // SPH_DROPIN_SYNC_MIRROR: wait for every step's snapshot
@@ -106,7 +107,9 @@ SPH::SPH()
 
    mSrcParticles = new Particle(mParticleCount);
    g_back = new Particle(mParticleCount);
-   for (int i = 0; i < mParticleCount; i++) mSrcParticles->mMass[i] = g_back->mMass[i] = 1.0f;
+   g_retired = new Particle(mParticleCount);
+   for (int i = 0; i < mParticleCount; i++)
+      mSrcParticles->mMass[i] = g_back->mMass[i] = g_retired->mMass[i] = 1.0f;
    g_sync_mirror = getenv("SPH_DROPIN_SYNC_MIRROR") != nullptr;
    mVoxelIds = new int[mParticleCount];
    mVoxelCoords = new vec3i[mParticleCount];
@@ -120,11 +123,11 @@ SPH::SPH()
                         mSrcParticles->mVelocity.data(), mSrcParticles->mMass.data()),
          "sph_hip_upload");
    // before the first snapshot arrives the GUI sees the initial condition in both mirrors
-   g_back->mPosition = mSrcParticles->mPosition;
-   g_back->mVelocity = mSrcParticles->mVelocity;
+   g_back->mPosition = g_retired->mPosition = mSrcParticles->mPosition;
+   g_back->mVelocity = g_retired->mVelocity = mSrcParticles->mVelocity;
    g_counts_front.assign(mGridCellCount, 0);
    g_counts_back.assign(mGridCellCount, 0);
-   for (Particle* p : {mSrcParticles, g_back}) {   // page-lock the mirrors (a failure only costs overlap)
+   for (Particle* p : {mSrcParticles, g_back, g_retired}) {   // page-lock the mirrors (a failure only costs overlap)
       (void)sph_hip_host_register(p->mPosition.data(), p->mPosition.size() * sizeof(float));
       (void)sph_hip_host_register(p->mVelocity.data(), p->mVelocity.size() * sizeof(float));
       (void)sph_hip_host_register(p->mDensity.data(), p->mDensity.size() * sizeof(float));
@@ -139,13 +142,17 @@ SPH::SPH()
 }
 
 // The snapshot that was travelling has arrived: it becomes what getParticles() / getGrid() show.
-// The GUI fetches the pointer every frame (src/visualization.cpp:145, 178); a frame that still
-// reads the old front buffer reads a complete older state - the buffer is not written again
-// before the NEXT swap.
+// The GUI fetches the pointer every frame (src/visualization.cpp:145, 178).  Three buffers: the
+// old front is RETIRED for one swap before it becomes the target of a copy again, so a frame that
+// fetched the pointer just before this swap goes on reading a complete older state - with two
+// buffers the same step() that swapped would at once start a DMA into what that frame reads.
+// (The per-voxel lists below are resized here, on the solver thread, while the GUI may call
+// count() on them: the reference's own clearGrid()/push_back race, src/sph.cpp:429-481.)
 static void publish_mirror()
 {
    Particle* filled = g_back;
-   g_back = *g_front_slot;
+   g_back = g_retired;
+   g_retired = *g_front_slot;
    *g_front_slot = filled;
    g_counts_front.swap(g_counts_back);
    for (int c = 0; c < g_cells; c++) {   // only count() is ever read from these lists

@@ -283,6 +283,10 @@ __device__ __forceinline__ uint32_t cell_of(const CellGrid& g, float x, float y,
 // inputs that round the other way (none above): those, and denormals, take sqrtf() - a squared
 // distance that small needs two fp32 positions 2^-51 apart, so the branch is there for
 // correctness, not for speed.
+// Non-finite inputs are outside the sweep on purpose: sqrt_rn(+inf) would be NaN (inf * rsq(inf) =
+// inf * 0) where sqrtf gives inf, but every call site takes the root of a squared distance that
+// has just passed "d2 < h2" - the membership test of src/sph.cpp:641,653, repeated bit for bit by
+// the acceleration pass on the same positions - and neither +inf nor NaN passes that test.
 #ifndef SPH_SQRT_GENERIC
 __device__ __forceinline__ float sqrt_rn(float x)
 {
