@@ -780,6 +780,62 @@ __device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairC
    __syncthreads();
 }
 
+// A workgroup whose tile fitted the density pass (12 B per entry) but not this pass's capacity
+// (16 B per entry): its neighbour lists exist, so it does not have to search again as the untiled
+// route does (every candidate of 27 cells through L1/L2, ~8x a tiled workgroup) - one lane walks
+// its list and gathers {x, y, z, m} and C of each neighbour from global memory instead of the LDS
+// tile (~2.5x a tiled workgroup).  Same pairs, same order, same arithmetic: same bits.  d = the
+// workgroup's tile descriptor (in LDS: the entries' segment -> sorted position shift).
+template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
+__device__ __forceinline__ float4
+accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const TileDesc& d,
+                 const float4* __restrict__ posm, const float4* __restrict__ velB,
+                 const float* __restrict__ rho, const float* __restrict__ auxc, const PairConsts& k)
+{
+   const float4 pi = posm[p];
+   AccelState s;
+   accel_begin(k, s, pi, velB[p], rho[p]);
+   const bool in_range = accel_operands_in_range(k);
+   int first_v = 0;
+   if (FAST) {
+      const int keep = visc_keep(s.visc_scale);
+      first_v = keep < cnt ? cnt - keep : 0;
+   }
+   constexpr int U = 4;
+   for (int j0 = 0; j0 < cnt; j0 += U) {
+      float4 pj[U], vj[U];
+      float cj[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         const int j = min(j0 + u, cnt - 1);
+         const uint32_t word = my_list[(j >> 1) * TILE_THREADS];
+         const uint32_t e = (j & 1) ? word >> 16 : word & 0xffffu;
+         const int q = ListEntry<WIDE>::tile(e) - ListEntry<WIDE>::shift(d, e);
+         pj[u] = posm[q];
+         cj[u] = auxc[q];
+         vj[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+         if (!FAST || j >= first_v) vj[u] = velB[q];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         if (j0 + u < cnt) {
+            float dx, dy, dz;
+            const float d2 = dist2(pi.x, pi.y, pi.z, pj[u].x, pj[u].y, pj[u].z, dx, dy, dz);
+            float dd = sqrt_rn(d2);
+            if (!UNIT_SCALE) dd *= k.sim_scale;
+            if (FAST) {
+               const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, dd, cj[u]);
+               if (j0 + u >= first_v) accel_pair_fast_viscous(s, hd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
+            } else {
+               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, dd, UNIFORM_MASS ? pi.w : pj[u].w, vj[u].x, vj[u].y,
+                                      vj[u].z, vj[u].w, cj[u], in_range);
+            }
+         }
+      }
+   }
+   return accel_end<UNIT_SCALE>(k, s);
+}
+
 template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
 __global__ void __launch_bounds__(TILE_THREADS, ACCEL_BLOCKS)
 k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ velB,
@@ -826,7 +882,24 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       const int g0 = begin + (int)giveup[blockIdx.x] * TILE_THREADS;
       const int gp = g0 + tid;
       const bool mine = gp < end && gp >= ob && gp < oe && accel_part_has(part, g0, meta);
-      if (mine) accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
+      const int gwg = (int)giveup[blockIdx.x];
+      const uint32_t glists = nlist_overflow[gwg];   // 1: its tile did not fit the density pass either (no lists)
+      if (glists != 1u) {
+         // the lists are there: walk them, operands from global memory (accel_from_lists)
+         tile_desc_load(desc, gwg, L.desc);
+         if (mine) {
+            const int gcnt = ncount[gp];
+            const uint32_t* glist = nlist + (size_t)gwg * (size_t)(list_rows(list_cap) * TILE_THREADS) + tid;
+            if (glists == 2u && gcnt > 0 && glist[0] == NLIST_NO_LIST)
+               accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
+            else
+               acc[gp] = accel_from_lists<UNIT_SCALE, UNIFORM_MASS, WIDE, FAST>(gp, gcnt, glist, L.desc, posm, velB,
+                                                                                rho, auxc, k);
+         }
+         __syncthreads();   // L.desc is loaded again below, for this workgroup's own tile
+      } else if (mine) {
+         accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
+      }
       if (fs.on) {
          float4 gx = make_float4(0.f, 0.f, 0.f, 0.f), ga = gx;
          if (mine) {

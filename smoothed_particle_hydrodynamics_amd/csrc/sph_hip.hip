@@ -237,7 +237,7 @@ void allow_large_tiles()
 // do - launches too short to hide that must not have any).  Nothing reported yet: the level next
 // to 3008 entries.
 int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, const int* per_cu, int n,
-               const float* thr, float untiled_cost)
+               const float* thr, float untiled_cost, int over_other = -1, float listed_cost = 0.0f)
 {
    const int blocks = fb[TSTAT_BLOCKS];
    if (blocks <= 0) {
@@ -255,7 +255,11 @@ int pick_level(const sph_hip_context* ctx, const int* fb, const int* levels, con
       if (over > 0 && !hides_untiled && l + 1 < n) continue;
       const float f = (float)over / (float)blocks;
       const int b = per_cu[l] < 1 ? 1 : (per_cu[l] > 6 ? 6 : per_cu[l]);
-      const float cost = (1.0f - f) / thr[b] + untiled_cost * f;
+      // (acceleration pass: of the workgroups that do not fit, those that fitted the density pass
+      // have their lists and take the cheaper list-driven route without a tile)
+      float f_search = f;
+      if (over_other >= 0) f_search = (float)(over_other < over ? over_other : over) / (float)blocks;
+      const float cost = (1.0f - f) / thr[b] + untiled_cost * f_search + listed_cost * (f - f_search);
       if (cost < best_cost) {
          best_cost = cost;
          best = levels[l];
@@ -337,6 +341,12 @@ void pick_tile_caps(sph_hip_context* ctx)
    }
    if (ctx->tile_cap_forced > 0) {
       caps.cap_density = caps.cap_accel = ctx->tile_cap_forced;
+      // (tests: a smaller capacity for the acceleration pass alone sends the workgroups in between
+      // down its list-driven route without a tile)
+      if (const char* v = getenv("SPH_HIP_TILE_CAP_ACCEL")) {
+         const int c = atoi(v) / 32 * 32;
+         if (c >= 256 && c < caps.cap_accel) caps.cap_accel = c;
+      }
       caps.wide = ctx->tile_cap_forced > TILE_CAP_MAX;
       return;
    }
@@ -348,8 +358,11 @@ void pick_tile_caps(sph_hip_context* ctx)
    static const float accel_thr[7] = {0.0f, 0.40f, 0.68f, 0.87f, 0.98f, 1.0f, 1.0f};
    caps.cap_density = pick_level(ctx, fb, ctx->density_levels, ctx->density_per_cu,
                                  ctx->n_density_levels, density_thr, 6.0f);
+   int over_density = fb[TSTAT_BLOCKS];
+   for (int c = 0; c < caps.n_cand; c++)
+      if (caps.cand[c] == caps.cap_density) over_density = fb[TSTAT_OVER + c];
    caps.cap_accel = pick_level(ctx, fb, ctx->accel_levels, ctx->accel_per_cu, ctx->n_accel_levels,
-                               accel_thr, 8.0f);
+                               accel_thr, 8.0f, over_density, 2.5f);
    // both passes of a step read and write the same lists: one entry format for the two
    caps.wide = caps.cap_density > TILE_CAP_MAX || caps.cap_accel > TILE_CAP_MAX;
    static int debug_left = getenv("SPH_HIP_DEBUG") ? 6 : 0;

@@ -378,6 +378,48 @@ def test_full_fused_integrate_equals_the_separate_kernel(hiplib, monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("list_cap", [None, "30"])
+def test_full_workgroups_that_fit_the_density_pass_only_walk_their_lists(oracle, hiplib, monkeypatch, fast, list_cap):
+    """A tile entry is 12 bytes in the density pass and 16 in the acceleration pass: a workgroup can
+    fit the one and not the other.  It then has its neighbour lists and walks them with operands
+    from global memory instead of searching again (accel_from_lists) - same bits as the tiled route,
+    with and without particles that outgrew their list, in both arithmetics; exact mode also against
+    the oracle."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(60000, speed=0.05)
+    mass = (0.5 + scenes.uniform01(11, np.arange(mass.size))).astype(np.float32)
+    out = []
+    for accel_cap in (None, "1024"):
+        monkeypatch.setenv("SPH_HIP_TILE_CAP", "3008")
+        for k, v in (("SPH_HIP_TILE_CAP_ACCEL", accel_cap), ("SPH_HIP_LIST_CAP", list_cap)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL) as sph:
+            sph.setParticles(pos, vel, mass)
+            sph.run(2)
+            mid = sph.getParticles()
+            before = (mid.mPosition.copy(), mid.mVelocity.copy())
+            sph.step()
+            part = sph.getParticles()
+            ts = sph.tileStats()
+            if accel_cap is not None:
+                assert ts["capacity_acceleration"] == 1024 and ts["untiled_density"] == 0
+                assert ts["untiled_acceleration"] > 50, ts
+            out.append({k: getattr(part, k).copy() for k in ("mPosition", "mVelocity", "mDensity",
+                                                            "mAcceleration", "mNeighborCount")})
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    if not fast:
+        opos, ovel = before
+        ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+        assert np.array_equal(out[1]["mAcceleration"], ref["acc"])
+        assert np.array_equal(out[1]["mPosition"], opos)
+
+
 @pytest.mark.parametrize("n,tile_cap,list_cap,fast", [
     (61237, None, None, False),     # a last workgroup that is not full
     (61237, "512", None, False),    # every workgroup on the give-up list: integrated by the first workgroups
