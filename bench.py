@@ -135,8 +135,9 @@ def preflight(rank, world):
     in there is then a 'no', not a stuck or dead run."""
     if os.environ.get("SPH_BENCH_FORCE_P2P_FALLBACK") == "1":
         return False
-    store = "/tmp/sph_bench_preflight_%s_%s" % (os.environ.get("MASTER_PORT", "0"),
-                                                os.environ.get("TORCHELASTIC_RUN_ID", "run"))
+    # rendezvous file of the helpers: one per launch (all ranks of a launch are children of the same
+    # torch.distributed.run agent; a file left by an earlier launch must not be found again)
+    store = "/tmp/sph_bench_preflight_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
     cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", store, "--gpus", str(world)]
     try:
         ok = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S).returncode == 0
@@ -144,6 +145,11 @@ def preflight(rank, world):
         print("pre-flight helper of rank %d: no answer after %d s" % (rank, PREFLIGHT_TIMEOUT_S),
               file=sys.stderr, flush=True)
         ok = False
+    if rank == 0:
+        try:
+            os.remove(store)
+        except OSError:
+            pass
     return ok
 
 
