@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "sph_hip.h"
+#include <string.h>
 
 #ifndef M
 #define M 32
@@ -80,7 +81,8 @@ SPH::SPH()
    mKineticEnergyTotal(0.0f), mPotentialEnergyTotal(0.0f),
    mAngularMomentumTotal(vec3(0.0f, 0.0f, 0.0f))
 {
-   if (getenv("SPH_HIP_FULL")) g_mode = SPH_HIP_MODE_FULL;
+   if (const char* full = getenv("SPH_HIP_FULL"))   // "fast": FULL with the tolerance-mode pair arithmetic
+      g_mode = strcmp(full, "fast") == 0 ? SPH_HIP_MODE_FULL_FAST : SPH_HIP_MODE_FULL;
    check(sph_hip_params_default(&g_prm, 0.1f, 32, 32, 32), "sph_hip_params_default");
    // mirror the constants the GUI getters hand out
    mSimulationScale = g_prm.sim_scale;

@@ -214,6 +214,7 @@ struct sph_hip_context {
    int accel_levels[TILE_CANDS] = {0}, n_accel_levels = 0;
    int density_per_cu[TILE_CANDS] = {0}, accel_per_cu[TILE_CANDS] = {0};  // workgroups per CU at each level
    TileCaps caps = {};             // candidate capacities + the two chosen for the current step
+   int cand_kept[TILE_CANDS] = {0}, n_cand_kept = 0;   // the candidate list tile_feedback's counts belong to
 
    // REF-mode lists
    int32_t* vox = nullptr; // 3 ints per particle

@@ -338,6 +338,14 @@ void pick_tile_caps(sph_hip_context* ctx)
          if (a == v) na++;
          caps.cand[caps.n_cand++] = v;
       }
+      // The arithmetic was switched (sph_hip_set_arithmetic): other kernels, possibly other levels.
+      // The statistics the host holds were counted against the old candidate list: they stay valid
+      // when the list is the same, and mean nothing otherwise.
+      bool same = ctx->n_cand_kept == caps.n_cand;
+      for (int c = 0; same && c < caps.n_cand; c++) same = ctx->cand_kept[c] == caps.cand[c];
+      if (!same && ctx->n_cand_kept > 0 && ctx->tile_feedback) memset(ctx->tile_feedback, 0, TSTAT_COUNT * sizeof(int));
+      ctx->n_cand_kept = caps.n_cand;
+      for (int c = 0; c < caps.n_cand; c++) ctx->cand_kept[c] = caps.cand[c];
    }
    if (ctx->tile_cap_forced > 0) {
       caps.cap_density = caps.cap_accel = ctx->tile_cap_forced;
@@ -1107,7 +1115,6 @@ int sph_hip_set_arithmetic(sph_hip_context* ctx, int arithmetic)
    // the capacity levels belong to the kernels that run: worked out again at the next cell build,
    // and what the old kernels' levels reported means nothing for the new ones
    ctx->caps.n_cand = 0;
-   if (ctx->tile_feedback) memset(ctx->tile_feedback, 0, TSTAT_COUNT * sizeof(int));
    return SPH_HIP_OK;
 }
 
