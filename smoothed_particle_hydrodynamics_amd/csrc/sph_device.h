@@ -183,6 +183,7 @@ struct sph_hip_context {
    int use_tiled = 1;              // FULL mode: LDS-tiled kernels (0 = untiled everywhere)
    int prehashed = 0;              // the last integrate also did the next build's cell hash + counts
                                    // (2: a slab's fused step - owned entries only, see k_hash_tail)
+   int no_prehash = 0, no_fused_integrate = 0, no_fused_slab = 0;   // SPH_HIP_NO_* switches, read at creation
    int slab_fused = 0;             // the step in progress (step_begin .. step_end) is fused
    void* slab_msgs[2] = {nullptr, nullptr};   // its message buffers
    int slab_msg_capacity = 0;

@@ -722,8 +722,8 @@ int step_impl(sph_hip_context* ctx, bool timed)
    // a context that holds the whole grid and has never exchanged anything: the integrate also
    // hashes and counts for the next cell build - and the tiled acceleration pass does both itself
    const bool hash_too = ctx->mode == SPH_HIP_MODE_FULL && !ctx->had_exchange && ctx->plane_lo == 0 &&
-                         ctx->plane_hi == ctx->grid.nz_global && !getenv_flag("SPH_HIP_NO_PREHASH");
-   const bool fused = hash_too && ctx->use_tiled && ctx->n > 0 && !getenv_flag("SPH_HIP_NO_FUSED_INTEGRATE");
+                         ctx->plane_hi == ctx->grid.nz_global && !ctx->no_prehash;
+   const bool fused = hash_too && ctx->use_tiled && ctx->n > 0 && !ctx->no_fused_integrate;
    if ((rc = launch_accel(ctx, 0, nullptr, fused))) return rc;
    if (phases || sums) SPH_TRY(hipEventRecord(ev[5], st));
    if (fused) {
@@ -914,6 +914,10 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    ctx->prm = *params;
    ctx->mode = mode;
    ctx->fast = fast ? 1 : 0;
+   // diagnostic switches, read once per context (not once per step)
+   ctx->no_prehash = getenv_flag("SPH_HIP_NO_PREHASH");
+   ctx->no_fused_integrate = getenv_flag("SPH_HIP_NO_FUSED_INTEGRATE");
+   ctx->no_fused_slab = getenv_flag("SPH_HIP_NO_FUSED_SLAB");
    ctx->device = device;
    ctx->capacity = capacity;
 
@@ -1518,7 +1522,7 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
    // The two parts of the acceleration launch do the rest of the step themselves (FusedStep):
    // integrate into the other pair of state buffers, hash for the next build, and - the border
    // part - the messages.  SPH_HIP_NO_FUSED_SLAB=1 keeps k_slab_pack_early + k_integrate.
-   ctx->slab_fused = getenv_flag("SPH_HIP_NO_FUSED_SLAB") ? 0 : 1;
+   ctx->slab_fused = ctx->no_fused_slab ? 0 : 1;
    ctx->slab_msgs[0] = left_device;
    ctx->slab_msgs[1] = right_device;
    ctx->slab_msg_capacity = capacity_records;

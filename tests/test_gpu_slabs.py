@@ -106,6 +106,42 @@ def test_slabs_dam_break_uniform_mass_two_slabs(oracle, hiplib, overlap):
         s.close()
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-slab-step", "separate-kernels"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_in_tolerance_mode_equal_the_single_context_bit_for_bit(hiplib, monkeypatch, world, fused):
+    """SPH_HIP_ARITH_FAST on slab contexts (sph_hip_set_arithmetic): every fused operation is
+    written out, so the slabs' results - ghost densities recomputed locally included - are the
+    single FAST context's bits, with migration, early exchange on two streams, with the two parts
+    of the acceleration launch doing the rest of the step and with the separate kernels
+    (SPH_HIP_NO_FUSED_SLAB=1); unequal masses, moving block."""
+    import smoothed_particle_hydrodynamics_amd as S
+    if fused:
+        monkeypatch.delenv("SPH_HIP_NO_FUSED_SLAB", raising=False)
+    else:
+        monkeypatch.setenv("SPH_HIP_NO_FUSED_SLAB", "1")
+    p, pos, vel, mass = moving_block()
+    steps = 5
+    group, cuts = build_group(S, p, pos, vel, mass, world, "two-streams")
+    for s in group.slabs:
+        s.set_arithmetic(S.ARITH_FAST)
+    owned0 = [s.status()["owned"] for s in group.slabs]
+    for _ in range(steps):
+        group.step()
+    got = group.gather(mass.size)
+    for s in group.slabs:
+        assert s.status()["errors"] == 0
+    with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST) as one:
+        one.setParticles(pos, vel, mass)
+        one.run(steps)
+        part = one.getParticles()
+        for k, want in (("ncount", part.mNeighborCount), ("rho", part.mDensity), ("acc", part.mAcceleration),
+                        ("pos", part.mPosition), ("vel", part.mVelocity)):
+            assert np.array_equal(got[k], want), k
+    assert owned0 != [s.status()["owned"] for s in group.slabs]
+    for s in group.slabs:
+        s.close()
+
+
 def test_message_overflow_is_reported(hiplib):
     """a message buffer that is too small sets error bit 2 instead of corrupting memory"""
     import smoothed_particle_hydrodynamics_amd as S
