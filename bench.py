@@ -235,7 +235,9 @@ def reference_scene(S, steps=8, n=32768):
     }
 
 
-PROFILE = os.path.join(ROOT, "profiles", "r3_kernel_counters.json")
+# (tools/profile_round.sh points these at the files it has just written under gpurun_out/, which are
+# then committed under profiles/ with the same names)
+PROFILE = os.environ.get("SPH_BENCH_COUNTERS") or os.path.join(ROOT, "profiles", "r3_kernel_counters.json")
 
 
 def kernel_counters(n, arithmetic="fast"):
@@ -258,10 +260,10 @@ def kernel_counters(n, arithmetic="fast"):
                       "re-run tools/profile_round.sh" % (prof.get("csrc_sha16"), source_hash()))
     out = dict(prof["arithmetic"][arithmetic], csrc_sha16=prof["csrc_sha16"])
     return out, "profiles/%s, %s arithmetic (kernel sources %s)" % (
-        os.path.basename(PROFILE), arithmetic, prof["csrc_sha16"])
+        os.path.basename(PROFILE).replace("r3a_", "r3_"), arithmetic, prof["csrc_sha16"])
 
 
-PRICES = os.path.join(ROOT, "profiles", "r3_valu_prices.json")
+PRICES = os.environ.get("SPH_BENCH_PRICES") or os.path.join(ROOT, "profiles", "r3_valu_prices.json")
 
 
 def valu_issue(prof, pair_ms):

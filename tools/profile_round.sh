@@ -13,8 +13,6 @@ tag=${1:-r3}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py > $out/${tag}_bench.json
-cat $out/${tag}_bench.json
 args="bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-breaking-dam"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python3 $args > $out/${tag}_stats.log 2>&1
 find $out/${tag}_stats -name "*kernel_trace.csv" -delete
@@ -30,3 +28,7 @@ if [ -x build/ubench/valu3 ]; then
    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $out/${tag}_ubench_pmc2 -o run -- ./build/ubench/valu3 > $out/${tag}_ubench_pmc2.log 2>&1
 fi
 python3 tools/pmc_summary.py $tag
+# the bench line last, with the counters and prices just taken (they are committed under profiles/
+# with these names; bench.py checks the stamp against the kernel sources it runs)
+SPH_BENCH_COUNTERS=$out/${tag}_kernel_counters.json SPH_BENCH_PRICES=$out/${tag}_valu_prices.json python3 bench.py > $out/${tag}_bench.json
+cat $out/${tag}_bench.json
