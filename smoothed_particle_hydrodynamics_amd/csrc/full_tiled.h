@@ -377,7 +377,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                      uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
                      int tile_cap, int32_t* __restrict__ tile_stats,
                      const uint32_t* __restrict__ giveup, int* __restrict__ tile_feedback, int list_cap,
-                     double* __restrict__ epart_clear)
+                     double* __restrict__ epart_clear, int inline_giveups)
 {
    // A slab whose acceleration pass integrates (FusedStep) writes one pair of energy partial sums
    // per workgroup that owns particles; the others' must read zero whatever an earlier step left
@@ -398,7 +398,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const int tid = threadIdx.x;
    // the first workgroups of the launch start with the workgroups whose tile does not fit
    // (give-up list), untiled: their long latency then overlaps the rest of the launch
-   if ((int)blockIdx.x < tile_stats[TSTAT_GIVEUP_DENSITY]) {
+   // (inline_giveups = 0: k_full_density_chunked, launched before this kernel, has done them)
+   if (inline_giveups && (int)blockIdx.x < tile_stats[TSTAT_GIVEUP_DENSITY]) {
       const int gp = begin + (int)giveup[blockIdx.x] * TILE_THREADS + tid;
       if (gp < end)
          density_untiled<UNIT_SCALE, FAST>(gp, posm, cell_start, velp, g, k, rho_out, velB_out,
@@ -422,7 +423,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    tile_desc_load(desc, wg, sd);
    if (sd.total > tile_cap) {
       // tile does not fit: on the give-up lists, computed by the first workgroups of both passes
-      if (tid == 0) nlist_overflow[wg] = 1u;
+      // (or, with its lists, by k_full_density_chunked, which then has set the flag itself)
+      if (inline_giveups && tid == 0) nlist_overflow[wg] = 1u;
       return;
    }
    RowRanges r;
@@ -637,6 +639,210 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    }
 }
 
+// ---- density pass of the workgroups whose tile fits no capacity: one row segment at a time ----------
+// A scene several times denser than the benchmark's (a dam that really breaks compresses to 5x)
+// has workgroups whose nine row segments together exceed every LDS capacity the pass can run
+// with.  Inline, the tiled kernel computes such a workgroup "untiled": every lane walks its
+// candidates through L1/L2 (6-8x a tiled workgroup), writes no lists, and the acceleration pass
+// has to search again the same way.  This kernel is launched BEFORE the tiled one when the last
+// step reported many of them, and stages the candidates through the same LDS tile in pieces:
+// segment after segment (ascending = canonical order), chunk after chunk of at most tile_cap
+// sorted positions.  Per chunk: TEST + append + SUM exactly as the tiled kernel does them, with
+// the reference's unfused distance test applied directly (no screening: two packed operations
+// more per candidate pair, no list rewrite).  List entries are the indices of the workgroup's
+// VIRTUAL tile (the layout its descriptor describes, wherever it would have been): the
+// acceleration pass - for which the tile is too large as well - walks them with operands from
+// global memory (accel_from_lists).  Same neighbours, same order, same arithmetic: same bits.
+// A workgroup whose virtual tile does not fit the entry format (> 4064 / 16352 indices) and a
+// particle with more neighbours than its list holds keep the untiled walk.
+// (launch bounds: 4 workgroups per CU - the tiles of these workgroups allow fewer anyway, and at the
+// tiled kernel's 6 the uniform-mass instantiations spilled two registers to scratch)
+template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
+__global__ void __launch_bounds__(TILE_THREADS, 4)
+k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict__ velp,
+                       const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
+                       CellGrid g, PairConsts k, float* __restrict__ rho_out,
+                       float4* __restrict__ velB_out, float* __restrict__ auxc_out,
+                       int32_t* __restrict__ ncount, const TileDesc* __restrict__ desc,
+                       uint32_t* __restrict__ nlist, uint32_t* __restrict__ nlist_overflow,
+                       int tile_cap, int32_t* __restrict__ tile_stats,
+                       const uint32_t* __restrict__ giveup, int list_cap)
+{
+   __shared__ TileDesc sd;
+   __shared__ int list_overflow;
+   TileLds L;
+   L.x = tile_lds_dynamic;
+   L.y = L.x + (tile_cap + TILE_PAD);
+   L.z = L.y + (tile_cap + TILE_PAD);
+   const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
+   const int tid = threadIdx.x;
+   const int n_giveup = tile_stats[TSTAT_GIVEUP_DENSITY];
+   for (int gi = blockIdx.x; gi < n_giveup; gi += gridDim.x) {
+      const int wg = (int)giveup[gi];
+      const int p0 = begin + wg * TILE_THREADS;
+      const int p = p0 + tid;
+      const bool live = p < end;
+      __syncthreads();                      // the previous workgroup of this block is done with sd / the tile
+      if (tid == 0) list_overflow = 0;
+      tile_desc_load(desc, wg, sd);
+      if (sd.total + TILE_PAD > (1 << ListEntry<WIDE>::TBITS)) {
+         // its virtual tile cannot be indexed by a list entry: the untiled walk, no lists
+         if (live) density_untiled<UNIT_SCALE, FAST>(p, posm, cell_start, velp, g, k, rho_out, velB_out, auxc_out, ncount);
+         if (tid == 0) nlist_overflow[wg] = 1u;
+         continue;
+      }
+      float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+      RowRanges r;
+#pragma unroll
+      for (int kk = 0; kk < 9; kk++) r.s[kk] = r.e[kk] = 0;
+      if (live) {
+         pi = posm[p];
+         int cx, cy, cz;
+         cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
+         row_ranges(g, cell_start, cx, cy, cz, r);
+      }
+      // the workgroup's nine row segments as sorted ranges (as tile_desc works them out)
+      int cxa, cya, cza, cxb, cyb, czb;
+      const float4 pa = posm[p0], pb = posm[min(p0 + TILE_THREADS - 1, end - 1)];
+      const int c_first = (int)cell_of(g, pa.x, pa.y, pa.z, cxa, cya, cza);
+      const int c_last = (int)cell_of(g, pb.x, pb.y, pb.z, cxb, cyb, czb);
+      const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
+      uint32_t* list_block = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS);
+      uint16_t* const my_entries = reinterpret_cast<uint16_t*>(list_block + tid);
+      const uint32_t* sum_list = list_block + tid;
+      uint32_t half = 0, step = 1;
+      int count = 0;
+      float density = 0.0f;
+#pragma unroll 1
+      for (int kk = 0; kk < 9; kk++) {
+         const int off = ((kk / 3 - 1) * g.ny + (kk % 3 - 1)) * g.nx;
+         int lo = c_first + off - 1, hi = c_last + off + 1;
+         lo = lo < 0 ? 0 : lo;
+         hi = hi > g.ncells - 1 ? g.ncells - 1 : hi;
+         int G = 0, len = 0;
+         if (hi >= lo) {
+            G = (int)cell_start[lo];
+            len = (int)cell_start[hi + 1] - G;
+         }
+         const int D = sd.D[kk];
+         const uint32_t kbits = ListEntry<WIDE>::tag(kk);
+         const int rs = kk == 0 ? r.s[0] : kk == 1 ? r.s[1] : kk == 2 ? r.s[2] : kk == 3 ? r.s[3] : kk == 4 ? r.s[4]
+                      : kk == 5 ? r.s[5] : kk == 6 ? r.s[6] : kk == 7 ? r.s[7] : r.s[8];
+         const int re = kk == 0 ? r.e[0] : kk == 1 ? r.e[1] : kk == 2 ? r.e[2] : kk == 3 ? r.e[3] : kk == 4 ? r.e[4]
+                      : kk == 5 ? r.e[5] : kk == 6 ? r.e[6] : kk == 7 ? r.e[7] : r.e[8];
+         for (int c0 = G; c0 < G + len; c0 += tile_cap) {
+            const int have = min(tile_cap, G + len - c0);
+            __syncthreads();                 // the previous chunk's readers are done
+            for (int i = tid; i < have; i += TILE_THREADS) {
+               const float4 q = posm[c0 + i];
+               L.x[i] = q.x;
+               L.y[i] = q.y;
+               L.z[i] = q.z;
+            }
+            __syncthreads();
+            // this lane's candidates inside the chunk, as chunk-local slots
+            const int ts = max(rs - c0, 0), te = min(re - c0, have);
+            const int first_new = count;
+            for (int t0 = (ts < te) ? (ts & ~3) : te; __any(t0 < te); t0 += 32) {
+               uint32_t mask = 0;
+               if (t0 < te) {
+#pragma unroll
+                  for (int q8 = 0; q8 < 4; q8++) {
+                     const int t = t0 + 8 * q8;
+                     if (t < te) {
+                        uint32_t m8 = 0;
+#pragma unroll
+                        for (int hf = 0; hf < 2; hf++) {
+                           const f32x4 X = lds_read4(L.x, t + 4 * hf), Y = lds_read4(L.y, t + 4 * hf),
+                                       Z = lds_read4(L.z, t + 4 * hf);
+                           // the reference's own test on the reference's own value: (dx*dx + dy*dy) + dz*dz < h2
+                           const f32x2 dxa = px - f32x2{X.x, X.y}, dya = py - f32x2{Y.x, Y.y}, dza = pz - f32x2{Z.x, Z.y};
+                           const f32x2 dxb = px - f32x2{X.z, X.w}, dyb = py - f32x2{Y.z, Y.w}, dzb = pz - f32x2{Z.z, Z.w};
+                           const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
+                           const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                           m8 |= (uint32_t)(da.x < k.h2) << (4 * hf + 0);
+                           m8 |= (uint32_t)(da.y < k.h2) << (4 * hf + 1);
+                           m8 |= (uint32_t)(db.x < k.h2) << (4 * hf + 2);
+                           m8 |= (uint32_t)(db.y < k.h2) << (4 * hf + 3);
+                        }
+                        mask |= m8 << (8 * q8);
+                     }
+                  }
+                  const int lo_b = ts - t0, hi_b = te - t0;
+                  if (lo_b > 0) mask &= ~0u << lo_b;
+                  if (hi_b < 32) mask &= ~(~0u << hi_b);
+                  if (kk == 4) {
+                     const int sb = (p - c0) - t0;      // the particle itself
+                     if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
+                  }
+                  count += __builtin_popcount(mask);
+                  if (count > list_cap) {
+                     mask = 0u;
+                     count = list_cap + 1;
+                  }
+               }
+               const uint32_t ebase = kbits | (uint32_t)(c0 + D + t0);
+               while (__any(mask != 0u)) {
+                  if (mask != 0u) {
+                     const uint32_t bit = (uint32_t)__builtin_ctz(mask);
+                     mask &= mask - 1u;
+                     my_entries[half] = (uint16_t)(ebase + bit);
+                     half += step;
+                     step = 2 * TILE_THREADS - step;
+                  }
+               }
+            }
+            // SUM of what this chunk added, in list order (a lane reads what it has written: behind
+            // a barrier, as the tiled kernel's SUM is behind one)
+            __syncthreads();
+            if (count <= list_cap) {
+               for (int j = first_new; j < count; j++) {
+                  const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
+                  const uint32_t entry = (j & 1) ? word >> 16 : word & 0xffffu;
+                  const int t = ListEntry<WIDE>::tile(entry) - D - c0;
+                  float mj = pi.w;
+                  if (!UNIFORM_MASS) mj = posm[c0 + t].w;
+                  float dx, dy, dz;
+                  const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+                  if (FAST) {
+                     density_accumulate_fast<UNIT_SCALE>(k, mj, d2, density);
+                  } else {
+                     float d = sqrt_rn(d2);
+                     if (!UNIT_SCALE) d *= k.sim_scale;
+                     density_accumulate(k, mj, d, density);
+                  }
+               }
+            }
+         }
+      }
+      if ((count & 1) && count < list_cap) my_entries[half] = (uint16_t)0;
+      const bool overflowed = count > list_cap;
+      if (overflowed) {
+         list_overflow = 1;
+         list_block[tid] = NLIST_NO_LIST;
+      }
+      if (__any(overflowed)) {
+         const int without = __popcll(__ballot(overflowed));
+         if ((tid & (SPH_WAVE - 1)) == 0) atomicAdd(&tile_stats[TSTAT_NO_LIST], without);
+      }
+      __syncthreads();
+      if (tid == 0) nlist_overflow[wg] = list_overflow ? 2u : 0u;
+      if (live) {
+         if (overflowed) {
+            // more neighbours than the list holds: this lane alone walks its candidates through L1/L2
+            density_untiled<UNIT_SCALE, FAST>(p, posm, cell_start, velp, g, k, rho_out, velB_out, auxc_out, ncount);
+         } else {
+            rho_out[p] = density;
+            const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
+            const float4 v = velp[p];
+            velB_out[p] = make_float4(v.x, v.y, v.z, FAST ? bc.y : bc.x);
+            auxc_out[p] = FAST ? bc.x : bc.y;
+            ncount[p] = count;
+         }
+      }
+   }
+}
+
 // ---- acceleration pass: list-driven, no TEST ------------------------------------------------------
 // Same workgroups, same tile layout as the density pass (so its u16 list entries are valid
 // tile indices).  The pass is bound by the per-neighbour gathers, so the tile also holds the
@@ -846,7 +1052,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                    const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ nlist_overflow,
                    int tile_cap, const int32_t* __restrict__ tile_stats,
                    const uint32_t* __restrict__ giveup, int part, int list_cap,
-                   int* __restrict__ tile_feedback, FusedStep fs)
+                   int* __restrict__ tile_feedback, FusedStep fs, int tile_cap_density)
 {
    __shared__ AccelLds L;
    float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
@@ -912,7 +1118,11 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    if (gave_up == 1u) return;
    tile_desc_load(desc, wg, L.desc);
    const int total = L.desc.total;
-   if (total > tile_cap) return;  // does not fit this pass's wider entries: on the give-up list
+   // does not fit this pass's wider entries, or did not fit the density pass's capacity (then it
+   // may fit this one and have lists all the same - k_full_density_chunked writes them): either way
+   // it is on the give-up list and one of the first workgroups computes it.  Computing it here as
+   // well would integrate and count its particles twice.
+   if (total > tile_cap || total > tile_cap_density) return;
    int B[9], D[9];
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {

@@ -184,6 +184,9 @@ struct sph_hip_context {
    int prehashed = 0;              // the last integrate also did the next build's cell hash + counts
                                    // (2: a slab's fused step - owned entries only, see k_hash_tail)
    int no_prehash = 0, no_fused_integrate = 0, no_fused_slab = 0;   // SPH_HIP_NO_* switches, read at creation
+   hipStream_t chunk_stream = nullptr;          // k_full_density_chunked runs beside the tiled density pass
+   hipEvent_t ev_chunk_fork = nullptr, ev_chunk_join = nullptr;
+   int chunked_giveups = -1;       // SPH_HIP_CHUNKED: 1 always / 0 never launch k_full_density_chunked (-1: by count)
    int slab_fused = 0;             // the step in progress (step_begin .. step_end) is fused
    void* slab_msgs[2] = {nullptr, nullptr};   // its message buffers
    int slab_msg_capacity = 0;

@@ -125,6 +125,12 @@ void free_all(sph_hip_context* ctx)
    }
    for (int k = 0; k < 2; k++)
       if (ctx->ev_pace[k]) (void)hipEventDestroy(ctx->ev_pace[k]);
+   if (ctx->chunk_stream) {
+      (void)hipStreamSynchronize(ctx->chunk_stream);
+      (void)hipStreamDestroy(ctx->chunk_stream);
+      if (ctx->ev_chunk_fork) (void)hipEventDestroy(ctx->ev_chunk_fork);
+      if (ctx->ev_chunk_join) (void)hipEventDestroy(ctx->ev_chunk_join);
+   }
    if (ctx->ev_density) (void)hipEventDestroy(ctx->ev_density);
    if (ctx->ev_border) (void)hipEventDestroy(ctx->ev_border);
    if (ctx->tile_feedback) (void)hipHostFree(ctx->tile_feedback);
@@ -221,6 +227,8 @@ void allow_large_tiles()
    for (int m = 0; m < 16; m++) {
       bind_flags([&](auto U, auto M, auto W, auto F) {
          (void)hipFuncSetAttribute((const void*)(k_full_density_tiled<U.value, M.value, W.value, F.value>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         (void)hipFuncSetAttribute((const void*)(k_full_density_chunked<U.value, M.value, W.value, F.value>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, most);
          if constexpr (M.value || !F.value)   // (FAST never gathers masses: only its M = true form exists)
             (void)hipFuncSetAttribute((const void*)(k_full_accel_lists<U.value, M.value, W.value, F.value>),
@@ -354,6 +362,12 @@ void pick_tile_caps(sph_hip_context* ctx)
       if (const char* v = getenv("SPH_HIP_TILE_CAP_ACCEL")) {
          const int c = atoi(v) / 32 * 32;
          if (c >= 256 && c < caps.cap_accel) caps.cap_accel = c;
+      }
+      // (... and a smaller one for the density pass alone: workgroups that fit the acceleration
+      // pass's capacity but are on the give-up lists all the same)
+      if (const char* v = getenv("SPH_HIP_TILE_CAP_DENSITY")) {
+         const int c = atoi(v) / 32 * 32;
+         if (c >= 256 && c < caps.cap_density) caps.cap_density = c;
       }
       caps.wide = ctx->tile_cap_forced > TILE_CAP_MAX;
       return;
@@ -531,14 +545,52 @@ void launch_density_tiled(sph_hip_context* ctx, bool unit, int blocks, const Pai
    // particles; this launch zeroes the others' - same grid, one pair per workgroup)
    const bool whole = ctx->plane_lo == 0 && ctx->plane_hi == ctx->grid.nz_global;
    double* epart_clear = whole ? nullptr : ctx->epart + 2;
+   // Many workgroups whose tile fits no capacity (a scene several times denser than the
+   // benchmark's): a launch of its own stages their candidates through LDS piece by piece and
+   // writes their lists (k_full_density_chunked) instead of the tiled kernel's first workgroups
+   // walking them untiled.  Decided from what the last step reported; both kernels read the same
+   // device-side list, the flag only says who works it off.
+   const int reported = ((volatile int*)ctx->tile_feedback)[TSTAT_GIVEUP_DENSITY];
+   const bool chunked = ctx->chunked_giveups == 1 || (ctx->chunked_giveups < 0 && reported >= 32);
+   // The two kernels work on disjoint workgroups: the chunked one runs beside the tiled one on a
+   // stream of its own (forked here, joined before anything else is enqueued) - alone it would
+   // leave the device to ~1 000 long workgroups while the other 15 000 wait.
+   hipStream_t side = ctx->stream;
+   if (chunked) {
+      if (!ctx->chunk_stream) {
+         if (hipStreamCreateWithFlags(&ctx->chunk_stream, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&ctx->ev_chunk_fork, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&ctx->ev_chunk_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->chunk_stream = nullptr;
+         }
+      }
+      if (ctx->chunk_stream && hipEventRecord(ctx->ev_chunk_fork, ctx->stream) == hipSuccess &&
+          hipStreamWaitEvent(ctx->chunk_stream, ctx->ev_chunk_fork, 0) == hipSuccess)
+         side = ctx->chunk_stream;
+   }
    bind_flags([&](auto U, auto M, auto W, auto F) {
+      if (chunked)
+         hipLaunchKernelGGL((k_full_density_chunked<U.value, M.value, W.value, F.value>), dim3(1024),
+                            dim3(TILE_THREADS), lds, side, ctx->posm[ctx->cur], ctx->velp[ctx->cur],
+                            ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc,
+                            ctx->ncount, ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap,
+                            ctx->tile_stats, ctx->giveup_density, ctx->list_cap);
       hipLaunchKernelGGL((k_full_density_tiled<U.value, M.value, W.value, F.value>), dim3(blocks),
                          dim3(TILE_THREADS), lds, ctx->stream, ctx->posm[ctx->cur], ctx->velp[ctx->cur],
                          ctx->cell_start, ctx->meta, ctx->grid, k, ctx->rho, ctx->velB, ctx->auxc,
                          ctx->ncount, ctx->tile_desc, ctx->nlist, ctx->nlist_overflow, cap,
                          ctx->tile_stats, ctx->giveup_density, ctx->tile_feedback, ctx->list_cap,
-                         epart_clear);
+                         epart_clear, chunked ? 0 : 1);
    }, unit, ctx->uniform_mass != 0, ctx->caps.wide != 0, ctx->fast != 0);
+   if (side != ctx->stream) {
+      // (a failure here would leave the streams unordered: drain the side stream the hard way)
+      if (hipEventRecord(ctx->ev_chunk_join, side) != hipSuccess ||
+          hipStreamWaitEvent(ctx->stream, ctx->ev_chunk_join, 0) != hipSuccess) {
+         (void)hipGetLastError();
+         (void)hipStreamSynchronize(side);
+      }
+   }
 }
 
 void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairConsts& k, int part,
@@ -573,7 +625,7 @@ void launch_accel_lists(sph_hip_context* ctx, bool unit, int blocks, const PairC
                          dim3(TILE_THREADS), lds, st, ctx->posm[ctx->cur], ctx->velB, ctx->rho, ctx->auxc,
                          ctx->ncount, ctx->cell_start, ctx->meta, ctx->grid, k, ctx->acc, ctx->tile_desc,
                          ctx->nlist, ctx->nlist_overflow, cap, ctx->tile_stats, ctx->giveup_accel, part,
-                         ctx->list_cap, ctx->tile_feedback, fs);
+                         ctx->list_cap, ctx->tile_feedback, fs, ctx->caps.cap_density);
    }, unit, ctx->uniform_mass != 0 || ctx->fast != 0, ctx->caps.wide != 0, ctx->fast != 0);
 }
 
@@ -918,6 +970,7 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    ctx->no_prehash = getenv_flag("SPH_HIP_NO_PREHASH");
    ctx->no_fused_integrate = getenv_flag("SPH_HIP_NO_FUSED_INTEGRATE");
    ctx->no_fused_slab = getenv_flag("SPH_HIP_NO_FUSED_SLAB");
+   if (const char* v = getenv("SPH_HIP_CHUNKED")) ctx->chunked_giveups = v[0] == '1' ? 1 : 0;   // default: by count
    ctx->device = device;
    ctx->capacity = capacity;
 

@@ -379,6 +379,65 @@ def test_full_fused_integrate_equals_the_separate_kernel(hiplib, monkeypatch):
 
 
 @pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("unequal", [True, False], ids=["unequal-masses", "unit-masses"])
+@pytest.mark.parametrize("tile_cap,list_cap", [("512", None), ("1504", None), ("1504", "30"), ("288", "6"),
+                                               ("3008/1024", None)])
+def test_full_workgroups_that_fit_no_capacity_are_staged_in_chunks(oracle, hiplib, monkeypatch, fast, unequal, tile_cap,
+                                                                   list_cap):
+    """k_full_density_chunked: a workgroup whose tile fits no LDS capacity gets its candidates staged
+    through the tile one chunk of a row segment at a time - lists written, the acceleration pass
+    walks them (accel_from_lists) - instead of the untiled walk.  Forced here by a pinned small
+    capacity (SPH_HIP_TILE_CAP) and SPH_HIP_CHUNKED=1, on a scene with a region 28x denser, unequal
+    masses, a moving state: same bits as the default routes, in both arithmetics; exact mode also
+    against the oracle.  288 entries = chunks far shorter than a row segment; 6-entry lists = most
+    particles outgrow their list and keep the untiled walk.  "3008/1024": the density pass's
+    capacity below the acceleration pass's - workgroups in between have lists AND would fit the
+    acceleration tile: they are on the give-up list and must be computed there only (computed twice,
+    the fused step integrates and counts their particles twice: the fault this case was added for)."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(60000, speed=0.05)
+    _, dense, _, _ = scenes.dam_break(60000, fill=(0.03, 0.3, 0.4))
+    pos = pos.copy()
+    pos[:3 * 20000] = dense[:3 * 20000]
+    if unequal:
+        mass = (0.5 + scenes.uniform01(11, np.arange(mass.size))).astype(np.float32)
+    out = []
+    density_cap = None
+    if "/" in tile_cap:
+        tile_cap, density_cap = tile_cap.split("/")
+    for chunked in (False, True):
+        for k, v in (("SPH_HIP_TILE_CAP", tile_cap if chunked else None),
+                     ("SPH_HIP_TILE_CAP_DENSITY", density_cap if chunked else None),
+                     ("SPH_HIP_LIST_CAP", list_cap if chunked else None),
+                     ("SPH_HIP_CHUNKED", "1" if chunked else "0")):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL) as sph:
+            sph.setParticles(pos, vel, mass)
+            sph.run(4)
+            mid = sph.getParticles()
+            before = (mid.mPosition.copy(), mid.mVelocity.copy())
+            sph.step()
+            part = sph.getParticles()
+            ts = sph.tileStats()
+            if chunked:
+                assert ts["untiled_density"] > 10, ts
+            out.append({k: getattr(part, k).copy() for k in ("mPosition", "mVelocity", "mDensity",
+                                                            "mAcceleration", "mNeighborCount")})
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    if not fast:
+        opos, ovel = before
+        ref = oracle.step(to_oracle_params(p), opos, ovel, mass, mode="full")
+        assert np.array_equal(out[1]["mNeighborCount"], ref["ncount"])
+        assert np.array_equal(out[1]["mDensity"], ref["rho"])
+        assert np.array_equal(out[1]["mAcceleration"], ref["acc"])
+
+
+@pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("list_cap", [None, "30"])
 def test_full_workgroups_that_fit_the_density_pass_only_walk_their_lists(oracle, hiplib, monkeypatch, fast, list_cap):
     """A tile entry is 12 bytes in the density pass and 16 in the acceleration pass: a workgroup can
