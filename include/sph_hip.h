@@ -308,6 +308,16 @@ int sph_hip_slab_download(sph_hip_context* ctx, int max_rows, int32_t* rows, uin
 /* Masses of the owned particles in the row order of sph_hip_slab_download (what a host needs,
  * with that call's arrays, to move particles to another slab: slab.py rebalance()). */
 int sph_hip_slab_download_mass(sph_hip_context* ctx, int max_rows, int32_t* rows, float* mass);
+/* Device-to-device re-partitioning (no counterpart in the reference): the owned particles as the
+ * 32-byte records of a halo message, {x,y,z,m | vx,vy,vz,id}, in cell-sorted order, written to
+ * DEVICE memory of the caller (*rows = their number; synchronises) - and a slab's owned particles
+ * from n such records in device memory (what sph_hip_slab_upload does from host arrays).  The rows
+ * that change owner when the cut planes move (slab.py rebalance()) can then travel over RCCL
+ * without touching the host. */
+int sph_hip_slab_export_records(sph_hip_context* ctx, void* device_records, int max_records,
+                                int32_t* rows);
+int sph_hip_slab_upload_records(sph_hip_context* ctx, const void* device_records, int n,
+                                int all_masses_equal);
 size_t sph_hip_slab_message_bytes(int capacity_records);
 /* NULL for a side without neighbour.  Call after sph_hip_step()/upload, before the transport. */
 int sph_hip_slab_pack(sph_hip_context* ctx, void* left_device, void* right_device,

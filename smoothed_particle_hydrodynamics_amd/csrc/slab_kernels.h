@@ -193,6 +193,29 @@ k_hash_tail(const float4* __restrict__ posm, int32_t* __restrict__ meta, CellGri
    }
 }
 
+// Device-to-device re-partitioning (slab.py rebalance()): the owned particles as message records
+// {x,y,z,m | vx,vy,vz,id} in cell-sorted order, and a slab's state from such records.
+__global__ void __launch_bounds__(256)
+k_export_records(const float4* __restrict__ posm, const float4* __restrict__ velp,
+                 const int32_t* __restrict__ meta, float4* __restrict__ rec)
+{
+   const int ob = meta[META_OWN_BEGIN];
+   const int p = ob + blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= meta[META_OWN_END]) return;
+   rec[2 * (p - ob)] = posm[p];
+   rec[2 * (p - ob) + 1] = velp[p];
+}
+
+__global__ void __launch_bounds__(256)
+k_import_records(const float4* __restrict__ rec, int n, float4* __restrict__ posm,
+                 float4* __restrict__ velp)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   posm[i] = rec[2 * i];
+   velp[i] = rec[2 * i + 1];
+}
+
 // Appends the records of the received messages behind the live entries [0, n_live) and sets
 // n_in, the entry count of the next cell build.  One launch for both messages.
 __global__ void __launch_bounds__(256)

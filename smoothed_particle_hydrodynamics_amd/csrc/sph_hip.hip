@@ -1186,9 +1186,10 @@ int sph_hip_get_params(const sph_hip_context* ctx, sph_hip_params* out)
 
 // shared by sph_hip_upload (ids = 0..n-1) and sph_hip_slab_upload (caller's global ids)
 static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const float* vel,
-                       const float* mass, const uint32_t* ids, int uniform_mass)
+                       const float* mass, const uint32_t* ids, int uniform_mass,
+                       const void* device_records = nullptr)
 {
-   if (n < 0 || (n > 0 && (!pos || !vel || !mass))) {
+   if (n < 0 || (n > 0 && !device_records && (!pos || !vel || !mass))) {
       ctx->err = "upload: null array or negative count";
       return SPH_HIP_ERR_INVALID;
    }
@@ -1210,7 +1211,12 @@ static int upload_impl(sph_hip_context* ctx, int n, const float* pos, const floa
    // before the first cell build everything uploaded is live and owned, in upload order
    const int32_t meta[META_COUNT] = {n, n, 0, n, 0, n, 0, 0};
    SPH_TRY(hipMemcpyAsync(ctx->meta, meta, sizeof(meta), hipMemcpyHostToDevice, ctx->stream));
-   if (n > 0) {
+   if (n > 0 && device_records) {
+      // the state is on the device already, as message records (sph_hip_slab_export_records)
+      hipLaunchKernelGGL(k_import_records, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream,
+                         (const float4*)device_records, n, ctx->posm[0], ctx->velp[0]);
+      SPH_TRY(hipGetLastError());
+   } else if (n > 0) {
       float* spos = ctx->stage;
       float* svel = spos + 3 * (size_t)n;
       float* smass = svel + 3 * (size_t)n;
@@ -1466,6 +1472,38 @@ int sph_hip_slab_download_mass(sph_hip_context* ctx, int max_rows, int32_t* rows
                           ctx->stream));
    SPH_TRY(hipStreamSynchronize(ctx->stream));
    return SPH_HIP_OK;
+}
+
+int sph_hip_slab_export_records(sph_hip_context* ctx, void* device_records, int max_records, int32_t* rows)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   int32_t meta[META_COUNT];
+   if ((rc = owned_count(ctx, meta))) return rc;
+   ctx->err_watch[0] = meta[META_ERRORS];
+   if ((rc = watch_check(ctx, "sph_hip_slab_export_records"))) return rc;
+   if (rows) *rows = ctx->n_owned;
+   if (!device_records || ctx->n_owned > max_records) {
+      ctx->err = "sph_hip_slab_export_records: caller's buffer is missing or too small";
+      return SPH_HIP_ERR_CAPACITY;
+   }
+   if (ctx->n_owned == 0) return SPH_HIP_OK;
+   hipLaunchKernelGGL(k_export_records, dim3(div_up(ctx->n_owned, 256)), dim3(256), 0, ctx->stream,
+                      ctx->posm[ctx->cur], ctx->velp[ctx->cur], ctx->meta, (float4*)device_records);
+   SPH_TRY(hipGetLastError());
+   SPH_TRY(hipStreamSynchronize(ctx->stream));
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_upload_records(sph_hip_context* ctx, const void* device_records, int n, int all_masses_equal)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   if (ctx->mode != SPH_HIP_MODE_FULL || n < 0 || (n > 0 && !device_records)) {
+      ctx->err = "sph_hip_slab_upload_records: FULL-mode contexts only, records required";
+      return SPH_HIP_ERR_INVALID;
+   }
+   return upload_impl(ctx, n, nullptr, nullptr, nullptr, nullptr, all_masses_equal ? 1 : 0, device_records);
 }
 
 int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors)

@@ -101,6 +101,8 @@ PROTOTYPES = {
     "sph_hip_slab_download": (C.c_int, [_ctx, C.c_int, _P(C.c_int32), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sph_hip_slab_download_mass": (C.c_int, [_ctx, C.c_int, _P(C.c_int32), C.c_void_p]),
+    "sph_hip_slab_export_records": (C.c_int, [_ctx, C.c_void_p, C.c_int, _P(C.c_int32)]),
+    "sph_hip_slab_upload_records": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "sph_hip_slab_message_bytes": (C.c_size_t, [C.c_int]),
     "sph_hip_slab_pack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
     "sph_hip_slab_unpack": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),

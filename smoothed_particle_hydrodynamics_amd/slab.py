@@ -208,6 +208,30 @@ class HipSlab:
             out.append(int(m[:4].view(self._torch.int32)[0].item()) if m is not None else 0)
         return tuple(out)
 
+    def export_records(self):
+        """The owned particles as message records, float32 [n, 8] = {x,y,z,m,vx,vy,vz,id bits}, in a
+        tensor on the slab's device (sph_hip_slab_export_records): the state never visits the host."""
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            buf = torch.empty((self.capacity, 8), dtype=torch.float32, device=self.device)
+        rows = C.c_int32()
+        self._check(self._lib.sph_hip_slab_export_records(self._ctx, C.c_void_p(buf.data_ptr()),
+                                                          self.capacity, C.byref(rows)),
+                    "sph_hip_slab_export_records")
+        return buf[:rows.value]
+
+    def upload_records(self, records, all_masses_equal):
+        """This slab's owned particles from float32 [n, 8] message records on its device
+        (sph_hip_slab_upload_records); the caller has ordered them by persistent id."""
+        torch = self._torch
+        rec = records.contiguous()
+        assert rec.dtype == torch.float32 and rec.device == self.device and rec.shape[-1] == 8
+        self.all_masses_equal = bool(all_masses_equal)
+        self._torch.cuda.current_stream(self.device).synchronize()   # the records were made on torch's stream
+        self._check(self._lib.sph_hip_slab_upload_records(self._ctx, C.c_void_p(rec.data_ptr()),
+                                                          int(rec.shape[0]), int(all_masses_equal)),
+                    "sph_hip_slab_upload_records")
+
     def download_mass(self):
         """Masses of the owned particles, in the row order of download()."""
         cap = self.capacity
@@ -595,6 +619,7 @@ class DistSlabStepper:
         self.make_slab, self.cuts = make_slab, (list(cuts) if cuts is not None else None)
         self.rebalance_every, self.imbalance, self.trim_every = rebalance_every, imbalance, trim_every
         self.rebalances = 0
+        self.device_rebalances = 0      # ... of them without the host in the data path
         self.message_growths = 0
         self._trimmed = False           # trim_messages() has been used: all ranks poll from then on
         self._primed = False
@@ -678,6 +703,8 @@ class DistSlabStepper:
         counts = np.array([int(t.item()) for t in every], np.float64)
         if not force and counts.max() <= self.imbalance * counts.mean():
             return False
+        if hasattr(slab, "export_records"):
+            return self._rebalance_on_device()
         d = slab.download()
         mass = slab.download_mass()
         pos3 = d["pos"].reshape(-1, 3)
@@ -738,6 +765,71 @@ class DistSlabStepper:
         self._primed = False            # the new slabs have no ghosts yet
         tr.forget()
         self.rebalances += 1
+        return True
+
+    def _rebalance_on_device(self):
+        """rebalance() without the host in the data path: the owned particles leave the slab as
+        message records in device memory (HipSlab.export_records), are sorted into their new
+        owners there, the rows that change owner travel point-to-point over the transport's own
+        group - device tensors over RCCL; over a gloo group (rehearsals on one GPU) only those rows
+        are staged through the host - and the new slab is filled from device records.  The
+        agreements (histogram, row counts) stay on the control group."""
+        import torch
+        dist, tr, slab = self.transport.dist, self.transport, self.slab
+        rank, world, group = tr.rank, tr.world, self._group()
+        cdev = self._device()
+        rec = slab.export_records()                       # float32 [n, 8] on the slab's device
+        p = slab.params
+        nz = int(p.full_cells_z)
+        c = torch.floor(rec[:, 2] * float(np.float32(p.full_cell_inv)))      # plane_of(), on the device
+        c = torch.where(torch.isfinite(c), c, torch.full_like(c, -1.0))
+        planes = torch.clamp(c, 0, nz - 1).to(torch.int64)
+        hist = torch.bincount(planes, minlength=nz).to(torch.int64).to(cdev)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        hist = hist.cpu().numpy()
+        new_cuts = cuts_from_histogram(hist, world)
+        if new_cuts == self.cuts:
+            return False
+        bounds = torch.tensor(new_cuts[1:], dtype=torch.int64, device=rec.device)
+        dest = torch.bucketize(planes, bounds, right=True)
+        out = [rec[dest == r].contiguous() for r in range(world)]
+        mine = torch.tensor([o.shape[0] for o in out], dtype=torch.int64, device=cdev)
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine, group=group)          # table[s][r] = rows s sends to r
+        data_group = tr.group
+        on_device = dist.get_backend(data_group) == "nccl"
+        ops, inbox, keep_alive = [], {}, []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            if out[peer].shape[0]:
+                t = out[peer] if on_device else out[peer].cpu()
+                keep_alive.append(t)
+                ops.append(dist.P2POp(dist.isend, t, peer, data_group))
+            n_in = int(table[peer][rank].item())
+            if n_in:
+                inbox[peer] = torch.empty((n_in, 8), dtype=torch.float32,
+                                          device=rec.device if on_device else "cpu")
+                ops.append(dist.P2POp(dist.irecv, inbox[peer], peer, data_group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if on_device:
+            torch.cuda.synchronize()
+        parts = [out[rank]] + [inbox[k].to(rec.device) for k in sorted(inbox)]
+        rows = torch.cat(parts) if len(parts) > 1 else parts[0]
+        ids = rows[:, 7].contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+        rows = rows[torch.argsort(ids, stable=True)].contiguous()
+        new_slab = self.make_slab(new_cuts, rank, hist)
+        new_slab.upload_records(rows, bool(getattr(slab, "all_masses_equal", False)))
+        new_slab.msg_active = min(getattr(slab, "msg_active", new_slab.msg_capacity), new_slab.msg_capacity)
+        new_slab.apply_settings(slab.settings())
+        slab.close()
+        self.slab, self.cuts = new_slab, list(new_cuts)
+        self._primed = False            # the new slabs have no ghosts yet
+        tr.forget()
+        self.rebalances += 1
+        self.device_rebalances += 1
         return True
 
     def step(self):

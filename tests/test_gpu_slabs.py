@@ -142,6 +142,40 @@ def test_slabs_in_tolerance_mode_equal_the_single_context_bit_for_bit(hiplib, mo
         s.close()
 
 
+def test_records_leave_and_enter_a_slab_on_the_device(hiplib):
+    """sph_hip_slab_export_records / _upload_records: the owned particles as message records in
+    device memory and back into a fresh slab - what rebalance() moves between ranks.  The second
+    slab steps to the same bits as the first."""
+    import torch
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    p, pos, vel, mass = moving_block(20000)
+    a = SL.HipSlab(p, 0, p.full_cells_z, 30000, 64, device=0, has_left=False, has_right=False)
+    a.upload(np.arange(mass.size, dtype=np.uint32), pos, vel, mass, all_masses_equal=False)
+    a.step()
+    rec = a.export_records()
+    assert rec.shape == (mass.size, 8) and rec.is_cuda
+    ids = rec[:, 7].contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+    assert sorted(ids.cpu().tolist()) == list(range(mass.size))
+    rows = rec[torch.argsort(ids, stable=True)].contiguous()
+    da = a.download()
+    order = np.argsort(da["ids"], kind="stable")
+    assert np.array_equal(rows[:, 0:3].cpu().numpy(), da["pos"].reshape(-1, 3)[order])
+    assert np.array_equal(rows[:, 3].cpu().numpy(), mass)
+    b = SL.HipSlab(p, 0, p.full_cells_z, 30000, 64, device=0, has_left=False, has_right=False)
+    b.upload_records(rows, all_masses_equal=False)
+    a.step()
+    b.step()
+    da, db = a.download(), b.download()
+    oa, ob = np.argsort(da["ids"], kind="stable"), np.argsort(db["ids"], kind="stable")
+    for k in ("pos", "vel", "acc"):
+        assert np.array_equal(da[k].reshape(-1, 3)[oa], db[k].reshape(-1, 3)[ob]), k
+    for k in ("rho", "ncount"):
+        assert np.array_equal(da[k][oa], db[k][ob]), k
+    a.close()
+    b.close()
+
+
 def test_message_overflow_is_reported(hiplib):
     """a message buffer that is too small sets error bit 2 instead of corrupting memory"""
     import smoothed_particle_hydrodynamics_amd as S
@@ -327,7 +361,7 @@ def _gpu_rebalance_worker(rank, world, port, steps, outdir):
         assert slab.status()["errors"] == 0
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), cuts0=np.array(cuts),
                  cuts=np.array(stepper.cuts), rebalances=stepper.rebalances,
-                 active=slab.msg_active, **d)
+                 device_rebalances=stepper.device_rebalances, active=slab.msg_active, **d)
         slab.close()
     finally:
         dist.destroy_process_group()
@@ -369,5 +403,8 @@ def test_rebalancing_and_trimmed_messages_on_the_gpu(hiplib, tmp_path):
         assert np.array_equal(d["acc"].reshape(-1, 3), part.mAcceleration.reshape(-1, 3)[ids])
         assert np.array_equal(d["ncount"], part.mNeighborCount[ids])
         assert int(d["rebalances"]) >= 1 and (d["cuts"] != d["cuts0"]).any()
+        # ... without the host in the data path: records exported, re-partitioned and uploaded on
+        # the device (only the rows that change owner cross the gloo group of this rehearsal)
+        assert int(d["device_rebalances"]) == int(d["rebalances"])
         assert int(d["active"]) < 20000
     assert seen.all()
