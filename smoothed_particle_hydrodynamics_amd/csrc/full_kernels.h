@@ -68,9 +68,7 @@ __device__ __forceinline__ void density_untiled(int p, const float4* __restrict_
          float dx, dy, dz;
          const float d2 = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz);
          if (d2 < k.h2) {
-            if (FAST) {
-               density_accumulate_fast<UNIT_SCALE>(k, pj.w, d2, density);
-            } else {
+            {
                float d = sqrtf(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                density_accumulate(k, pj.w, d, density);

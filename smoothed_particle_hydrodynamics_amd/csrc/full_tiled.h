@@ -552,9 +552,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             if (d2 < k.h2 && !(kk == 4 && t == self_t)) {
                float mj = pi.w;
                if (!UNIFORM_MASS) mj = posm[t - D].w;
-               if (FAST) {
-                  density_accumulate_fast<UNIT_SCALE>(k, mj, d2, density);
-               } else {
+               {
                   float d = sqrt_rn(d2);
                   if (!UNIT_SCALE) d *= k.sim_scale;
                   density_accumulate(k, mj, d, density);
@@ -589,9 +587,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
             float dx, dy, dz;
             const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
             if (d2 < k.h2) {             // the reference's own test, on the reference's own value
-               if (FAST) {
-                  density_accumulate_fast<UNIT_SCALE>(k, mj, d2, density);
-               } else {
+               {
                   float d = sqrt_rn(d2);
                   if (!UNIT_SCALE) d *= k.sim_scale;
                   density_accumulate(k, mj, d, density);
@@ -804,9 +800,7 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                   if (!UNIFORM_MASS) mj = posm[c0 + t].w;
                   float dx, dy, dz;
                   const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-                  if (FAST) {
-                     density_accumulate_fast<UNIT_SCALE>(k, mj, d2, density);
-                  } else {
+                  {
                      float d = sqrt_rn(d2);
                      if (!UNIT_SCALE) d *= k.sim_scale;
                      density_accumulate(k, mj, d, density);

@@ -26,21 +26,14 @@ __device__ __forceinline__ void density_accumulate(const PairConsts& k, float ma
 // bar is 1e-4 relative on forces.  The FAST variants keep what decides WHICH pairs are summed and
 // in WHICH order (the exact unfused d2 < h2 membership test, the canonical order, the rescale of the
 // viscous sum inside the neighbour loop) and evaluate the per-pair arithmetic the way such a build
-// may: fused multiply-adds, no detour through the square root where only d^2 is needed
-// (computeDensity), fp32 reciprocal instead of the fp64 quotient of src/sph.cpp:854-856.  Every fused operation is written out (the translation unit is compiled with
+// may - in the ACCELERATION sum only: fp32 reciprocal instead of the fp64 quotient of
+// src/sph.cpp:854-856, fused accumulation, a viscous sum that leaves out terms below 1e-20.  The
+// density sum stays the reference's arithmetic bit for bit: the pressure p = (rho - rho0) * k
+// amplifies a relative error of rho by rho / (rho - rho0), and a first version that summed
+// h^2 - d^2 without the square root (2e-6 off in rho) was 4e-4 off in the acceleration of
+// particles next to one whose density is within a per cent of rho0.  Every fused operation is written out (the translation unit is compiled with
 // -ffp-contract=off), so all routes - tiled, untiled, the walk of a particle without a list, any
 // slab count - produce the same bits as each other.
-
-// computeDensity's inner term from the squared distance: t = h^2 - d^2 without sqrt and re-squaring.
-// d2 is the reference's unfused (dx*dx + dy*dy) + dz*dz, already known to be < h2.
-template <bool UNIT_SCALE>
-__device__ __forceinline__ void density_accumulate_fast(const PairConsts& k, float mass, float d2,
-                                                        float& density)
-{
-   float t = UNIT_SCALE ? (k.hscaled2 - d2) : __builtin_fmaf(-d2, k.sim_scale * k.sim_scale, k.hscaled2);
-   const float w = (t * t) * t;
-   density = __builtin_fmaf(mass * k.kernel1, w, density);
-}
 
 // Quantities of neighbour j that computeAcceleration re-derives for every pair
 // (reference src/sph.cpp:829-834, 860, 871).  They depend on j only, so they are computed once

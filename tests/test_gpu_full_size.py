@@ -163,8 +163,9 @@ def test_c3_moved_state_window_tolerance_mode(oracle, moved_run):
     # and over the whole scene against the exact mode (= the oracle wherever it was checked)
     rel = vec_rel(got["acc"], r["exact"]["acc"])
     assert (rel > 1e-4).mean() <= 1e-4, "%d of %d particles beyond 1e-4" % ((rel > 1e-4).sum(), rel.size)
-    print("C3 window, tolerance mode: max force rel err %.3g, max density err %.3g of a term; whole scene vs "
-          "exact mode: max %.3g, %d beyond 1e-4" % (worst[0], worst[1], rel.max(), (rel > 1e-4).sum()))
+    assert np.array_equal(got["rho"], r["exact"]["rho"])        # the density sum is the exact mode's
+    print("C3 window, tolerance mode: max force rel err %.3g; whole scene vs exact mode: max %.3g, %d beyond "
+          "1e-4" % (worst[0], rel.max(), (rel > 1e-4).sum()))
 
 
 def test_c3_two_slabs_identical(big_run):

@@ -68,3 +68,39 @@ def test_random_scene(oracle, hiplib, case, mode):
             assert np.array_equal(part.mAcceleration, ref["acc"], equal_nan=True), what + "acceleration"
             assert np.array_equal(part.mPosition, opos, equal_nan=True), what + "position"
             assert np.array_equal(part.mVelocity, ovel, equal_nan=True), what + "velocity"
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_random_scene_tolerance_mode(oracle, hiplib, case):
+    """the same draws with SPH_HIP_MODE_FULL_FAST, held to tests/test_gpu_full_fast.py's bar (every
+    step started from the state the GPU started from)"""
+    import smoothed_particle_hydrodynamics_amd as S
+    from test_gpu_full_fast import check_fast
+    from helpers import vec_rel
+    p, pos, vel, mass = draw(case)
+    op = to_oracle_params(p)
+    cur_pos, cur_vel = pos.copy(), vel.copy()
+    with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST) as sph:
+        sph.setParticles(pos, vel, mass)
+        for step in range(2):
+            sph.step()
+            part = sph.getParticles()
+            opos, ovel = cur_pos.copy(), cur_vel.copy()
+            ref = oracle.step(op, opos, ovel, mass, mode="full")
+            what = "case %d (fast, n=%d) step %d" % (case, mass.size, step)
+            finite = np.isfinite(ref["acc"]).reshape(-1, 3).all(axis=1) & np.isfinite(ref["rho"])
+            assert np.array_equal(np.isfinite(part.mAcceleration).reshape(-1, 3).all(axis=1), finite), what
+
+            class Part:
+                pass
+            sel = Part()
+            sel.mNeighborCount = part.mNeighborCount
+            sel.mDensity = np.where(finite, part.mDensity, 0).astype(np.float32)
+            sel.mAcceleration = np.where(np.repeat(finite, 3), part.mAcceleration, 0).astype(np.float32)
+            want = dict(ncount=ref["ncount"], rho=np.where(finite, ref["rho"], 0).astype(np.float32),
+                        acc=np.where(np.repeat(finite, 3), ref["acc"], 0).astype(np.float32))
+            check_fast(sel, want, p, mass, what,
+                       scale=lambda: np.maximum(oracle.full_accel_scale(op, cur_pos, cur_vel, mass, ref["rho"]), 1e-300))
+            ok = np.repeat(finite, 3)
+            assert vec_rel(np.where(ok, part.mVelocity, 0), np.where(ok, ovel, 0)).max() <= 1e-4, what + " velocity"
+            cur_pos, cur_vel = part.mPosition.copy(), part.mVelocity.copy()
