@@ -83,6 +83,9 @@ static_assert(NLIST_CAP <= NLIST_CAP_MAX, "initial list capacity");
 #ifndef ACCEL_UNROLL
 #define ACCEL_UNROLL 8
 #endif
+#ifndef VISC_UNROLL
+#define VISC_UNROLL 4     // neighbours per trip of the tolerance-mode viscous sum (the list's last few)
+#endif
 // A 16-bit list entry is a tile index plus what it takes to get back from it to the neighbour's
 // sorted position (tile index - D[segment]).  Narrow (tiles up to 4064 entries): segment id << 12 |
 // 12-bit index.  Wide (scenes several times denser, tiles up to 16352 entries, chosen per step by
@@ -1024,8 +1027,8 @@ accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const Til
             float dd = sqrt_rn(d2);
             if (!UNIT_SCALE) dd *= k.sim_scale;
             if (FAST) {
-               const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, dd, cj[u]);
-               if (j0 + u >= first_v) accel_pair_fast_viscous(s, hd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, cj[u]);
+               if (j0 + u >= first_v) accel_pair_fast_viscous(k, s, dd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
             } else {
                accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, dd, UNIFORM_MASS ? pi.w : pj[u].w, vj[u].x, vj[u].y,
                                       vj[u].z, vj[u].w, cj[u], in_range);
@@ -1076,6 +1079,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // 1: tile did not fit the density pass (on the give-up list), 2: some particle of the
    // workgroup has no list (more neighbours than list_cap)
    const uint32_t gave_up = own ? nlist_overflow[wg] : 1u;
+   // (requested together with the flag it would otherwise wait for - one round trip less in front
+   // of the tile loads; kept in a register while a give-up workgroup uses L.desc)
+   int desc_word = 0;
+   if (tid < (int)(sizeof(TileDesc) / sizeof(int))) desc_word = reinterpret_cast<const int*>(&desc[wg])[tid];
    // the first workgroups of the launch start with the workgroups whose tile does not fit
    // (give-up list), untiled, so that their long latency overlaps the rest of the launch
    if ((int)blockIdx.x < tile_stats[TSTAT_GIVEUP_ACCEL]) {
@@ -1110,7 +1117,8 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       }
    }
    if (gave_up == 1u) return;
-   tile_desc_load(desc, wg, L.desc);
+   if (tid < (int)(sizeof(TileDesc) / sizeof(int))) reinterpret_cast<int*>(&L.desc)[tid] = desc_word;
+   __syncthreads();
    const int total = L.desc.total;
    // does not fit this pass's wider entries, or did not fit the density pass's capacity (then it
    // may fit this one and have lists all the same - k_full_density_chunked writes them): either way
@@ -1157,6 +1165,14 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       cnt = ncount[p];
    }
 
+   // the lane's first list words travel with the tile (requested before the count is known: what
+   // a lane with fewer entries reads in the rows of its block is never used)
+   const uint32_t* my_list = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS) + col;
+   uint32_t entry[ACCEL_UNROLL], next_word[ACCEL_UNROLL / 2];
+   const int last_row = list_rows(list_cap) - 1;
+#pragma unroll
+   for (int u = 0; u < ACCEL_UNROLL / 2; u++) next_word[u] = my_list[(u < last_row ? u : last_row) * TILE_THREADS];
+
    // the tile: first batch from the registers, then whatever is left
 #pragma unroll
    for (int r = 0; r < BATCH; r++) {
@@ -1185,7 +1201,6 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    accel_begin(k, s, pi, vi, rho_i);
    // every listed pair passed the exact d2 < h2 test: the division's range checks are uniform
    const bool in_range = accel_operands_in_range(k);
-   const uint32_t* my_list = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS) + col;
    // a particle without a list (marker in its first word; only in workgroups flagged 2): its lane
    // skips the list loop and walks its candidate ranges in the tile afterwards
    bool no_list = false;
@@ -1201,14 +1216,67 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #if defined(SPH_ABLATE) && SPH_ABLATE == 21
    cnt = 0;   // timing only: prologue and epilogue
 #endif
+   const int lastw = cnt > 0 ? (cnt - 1) >> 1 : 0;
+   // (the words requested before the count was known: a lane past its last word takes that one
+   // again - the exact loop gathers by every entry it holds, used or not)
+#pragma unroll
+   for (int u = 1; u < ACCEL_UNROLL / 2; u++) next_word[u] = u <= lastw ? next_word[u] : next_word[u - 1];
+   if constexpr (FAST) {
+      // The pressure sum over the whole list: everything it needs of a neighbour is in the tile
+      // ({x, y, z, m B}), no gather.  The list entries of the NEXT trip are requested before this
+      // trip's arithmetic.  Lanes past their count re-read their last entry (result unused).
+      for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
+#pragma unroll
+         for (int u = 0; u < ACCEL_UNROLL; u++)
+            entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
+#pragma unroll
+         for (int u = 0; u < ACCEL_UNROLL / 2; u++) {
+            const int w = (j0 + ACCEL_UNROLL) / 2 + u;
+            next_word[u] = my_list[(w < lastw ? w : lastw) * TILE_THREADS];
+         }
+#pragma unroll
+         for (int u = 0; u < ACCEL_UNROLL; u++) {
+            if (j0 + u < cnt) {
+               const float4 pj = xyzc[ListEntry<WIDE>::tile(entry[u])];
+#if defined(SPH_ABLATE) && SPH_ABLATE == 22
+               s.pgx += pj.x + pj.w;   // timing only: no pair arithmetic
+#else
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, pj.w);
+#endif
+            }
+         }
+      }
+      // The viscous sum over the list's last visc_keep() entries (ascending, as everywhere): the
+      // only neighbours whose {v, C} is gathered, with the reference's stored distance.
+      const int nv = cnt - first_v;
+      for (int m0 = 0; __any(m0 < nv); m0 += VISC_UNROLL) {
+         float4 vj[VISC_UNROLL];
+         int tj[VISC_UNROLL];
+#pragma unroll
+         for (int u = 0; u < VISC_UNROLL; u++) {
+            const int j = min(first_v + m0 + u, cnt > 0 ? cnt - 1 : 0);
+            const uint32_t word = my_list[(j >> 1) * TILE_THREADS];
+            const uint32_t e = (j & 1) ? word >> 16 : word & 0xffffu;
+            tj[u] = ListEntry<WIDE>::tile(e);
+            vj[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + u < nv) vj[u] = velB[tj[u] - ListEntry<WIDE>::shift(L.desc, e)];
+         }
+#pragma unroll
+         for (int u = 0; u < VISC_UNROLL; u++) {
+            if (m0 + u < nv) {
+               const float4 pj = xyzc[tj[u]];
+               float dx, dy, dz;
+               float d = sqrt_rn(dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz));
+               if (!UNIT_SCALE) d *= k.sim_scale;
+               accel_pair_fast_viscous(k, s, d, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
+            }
+         }
+      }
+   } else {
    // ACCEL_UNROLL neighbours per trip: their {v,B} gathers are issued back to back before the
    // first pair's arithmetic, and the list entries of the NEXT trip are requested before it too,
    // so neither of a neighbour's two dependent memory round trips is waited for in isolation.
    // Lanes past their count re-read their last entry (valid address, result unused).
-   const int lastw = cnt > 0 ? (cnt - 1) >> 1 : 0;
-   uint32_t entry[ACCEL_UNROLL], next_word[ACCEL_UNROLL / 2];
-#pragma unroll
-   for (int u = 0; u < ACCEL_UNROLL / 2; u++) next_word[u] = my_list[(u < lastw ? u : lastw) * TILE_THREADS];
    for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
       float4 vj[ACCEL_UNROLL];
       float mj[ACCEL_UNROLL];
@@ -1216,22 +1284,14 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
          mj[u] = pi.w;
-         if (FAST) {
-            vj[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j0 + u >= first_v && j0 + u < cnt) {   // (lanes that skip it cost the texture path nothing)
-               const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
-               vj[u] = velB[q];
-            }
-         } else {
-            const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
-            const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
+         const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
+         const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
 #if defined(SPH_ABLATE) && SPH_ABLATE == 7
-            vj[u] = make_float4(1.f, 2.f, 3.f, 4.f);  // timing only: no gather
+         vj[u] = make_float4(1.f, 2.f, 3.f, 4.f);  // timing only: no gather
 #else
-            vj[u] = velB[qq];
+         vj[u] = velB[qq];
 #endif
-            if (!UNIFORM_MASS) mj[u] = posm[qq].w;
-         }
+         if (!UNIFORM_MASS) mj[u] = posm[qq].w;
       }
       // the next trip's list entries travel while this trip's pairs are computed
 #pragma unroll
@@ -1250,16 +1310,12 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #if defined(SPH_ABLATE) && SPH_ABLATE == 22
             s.pgx += d + vj[u].x + pj.w;   // timing only: no pair arithmetic
 #else
-            if (FAST) {
-               const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
-               if (j0 + u >= first_v) accel_pair_fast_viscous(s, hd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
-            } else {
-               accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
-                                      pj.w, in_range);
-            }
+            accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, d, mj[u], vj[u].x, vj[u].y, vj[u].z, vj[u].w,
+                                   pj.w, in_range);
 #endif
          }
       }
+   }
    }
    if (gave_up == 2u && __any(no_list) && no_list) {
       // canonical order: the 9 rows ascending, positions ascending inside a row
@@ -1281,10 +1337,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                if (FAST) {
-                  const float hd = accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
+                  accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, pj.w);
                   if (jw >= first_v) {
                      const float4 vj = velB[t - D];
-                     accel_pair_fast_viscous(s, hd, vj.x, vj.y, vj.z, vj.w);
+                     accel_pair_fast_viscous(k, s, d, vj.x, vj.y, vj.z, vj.w);
                   }
                   jw++;
                } else {

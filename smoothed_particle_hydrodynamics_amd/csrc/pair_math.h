@@ -157,18 +157,29 @@ __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, f
 
 // One neighbour, tolerance mode (see the top of this file): same terms, same place of the viscous
 // rescale; fp32 reciprocal for g = (k2 * r) / (d + 0.01) in place of the fp64 quotient, fused
-// accumulation.  (dx,dy,dz) = r_i - r_j and d = the stored distance exactly as in accel_pair - the
-// correctly rounded root of the unfused d2: both sums hang on h - d, which for a neighbour near
-// the rim of the kernel is a difference of nearly equal numbers, and the viscous sum is dominated
-// by its LAST neighbour (every earlier one is rescaled once more, :880-882), so an ulp of d there
-// is a relative error of ulp * h / (h - d) in the whole term - measured 1.5e-3 on accelerations
-// with a hardware square root on the fused d2.
+// accumulation.  (dx,dy,dz) = r_i - r_j.
+//
+// The two sums take the distance differently.  The PRESSURE sum weights a pair by (h - d)^2: a
+// relative error e of d is an error 2 e d (h - d) of the weight, which vanishes at the rim where
+// h - d cancels - it evaluates d as the hardware square root (1 ulp) of the fused d2
+// (fast_distance: 5 instructions for the correctly rounded root's 18).  The VISCOUS sum weights
+// by h - d and is dominated by its LAST neighbour (every earlier one is rescaled once more,
+// :880-882): an ulp of d there is a relative error of ulp * h / (h - d) in the whole sum - measured
+// 1.5e-3 on accelerations with the fast distance - so it keeps the reference's stored distance,
+// the correctly rounded root of the unfused d2, for the few neighbours it visits (visc_keep).
 // Bm = m_j * B: the density pass of a FAST context stores the product (neighbor_terms_fast), so no
-// route of the acceleration pass gathers masses.  Returns h - d for the viscous part.
-template <bool UNIT_SCALE>
-__device__ __forceinline__ float accel_pair_fast_pressure(const PairConsts& k, AccelState& s, float dx,
-                                                          float dy, float dz, float d, float Bm)
+// route of the acceleration pass gathers masses.
+__device__ __forceinline__ float fast_distance(float dx, float dy, float dz)
 {
+   return __builtin_amdgcn_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+}
+
+template <bool UNIT_SCALE>
+__device__ __forceinline__ void accel_pair_fast_pressure(const PairConsts& k, AccelState& s, float dx,
+                                                         float dy, float dz, float Bm)
+{
+   float d = fast_distance(dx, dy, dz);
+   if (!UNIT_SCALE) d *= k.sim_scale;
    const float rden = __builtin_amdgcn_rcpf(d + 0.01f);
    const float hd = k.hscaled - d;
    // pressure: (k2 * r / den) * (h - d)^2 * (m_j * A) * B
@@ -176,14 +187,13 @@ __device__ __forceinline__ float accel_pair_fast_pressure(const PairConsts& k, A
    s.pgx = __builtin_fmaf(dx, f, s.pgx);
    s.pgy = __builtin_fmaf(dy, f, s.pgy);
    s.pgz = __builtin_fmaf(dz, f, s.pgz);
-   return hd;
 }
 
-// viscosity, rescaled inside the neighbour loop (:880-882)
-__device__ __forceinline__ void accel_pair_fast_viscous(AccelState& s, float hd, float vjx, float vjy,
-                                                        float vjz, float C)
+// viscosity, rescaled inside the neighbour loop (:880-882); d = the stored distance as in accel_pair
+__device__ __forceinline__ void accel_pair_fast_viscous(const PairConsts& k, AccelState& s, float d,
+                                                        float vjx, float vjy, float vjz, float C)
 {
-   const float c2 = hd * C;
+   const float c2 = (k.hscaled - d) * C;
    s.vtx = __builtin_fmaf(vjx - s.vx, c2, s.vtx) * s.visc_scale;
    s.vty = __builtin_fmaf(vjy - s.vy, c2, s.vty) * s.visc_scale;
    s.vtz = __builtin_fmaf(vjz - s.vz, c2, s.vtz) * s.visc_scale;
