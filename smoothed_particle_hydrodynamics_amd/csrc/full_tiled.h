@@ -342,10 +342,21 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
 {
    const f32x4 X0 = lds_read4(L.x, t);
    const f32x4 X1 = lds_read4(L.x, t + 4);
+#if defined(SPH_ABLATE) && SPH_ABLATE == 14
+   const f32x4 Y0 = lds_read4(L.y, t);           // timing only: three LDS reads, no sign gathering
+   const f32x4 Y1 = X0;
+#else
    const f32x4 Y0 = lds_read4(L.y, t);
    const f32x4 Y1 = lds_read4(L.y, t + 4);
+#endif
+#if defined(SPH_ABLATE) && SPH_ABLATE == 14
+   const f32x4 Z0 = X1, Z1 = Y0;
+#elif defined(SPH_ABLATE) && SPH_ABLATE == 12
+   const f32x4 Z0 = Y0 + X1, Z1 = Y1 + X0;   // timing only: the same arithmetic on four LDS reads instead of six
+#else
    const f32x4 Z0 = lds_read4(L.z, t);
    const f32x4 Z1 = lds_read4(L.z, t + 4);
+#endif
    const f32x2 mh = {-h2, -h2};
    const f32x2 da = screen_pair(px, py, pz, f32x2{X0.x, X0.y}, f32x2{Y0.x, Y0.y}, f32x2{Z0.x, Z0.y}, mh);
    const f32x2 db = screen_pair(px, py, pz, f32x2{X0.z, X0.w}, f32x2{Y0.z, Y0.w}, f32x2{Z0.z, Z0.w}, mh);
@@ -353,6 +364,16 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
    const f32x2 dd = screen_pair(px, py, pz, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w}, mh);
    // inside the screen  <=>  sign bit of (d2 - h2); v_alignbit shifts the mask left and brings the
    // next sign in at bit 0 - slot 7 first, so that slot 0 ends in bit 0
+#if defined(SPH_ABLATE) && SPH_ABLATE == 14
+   {  // four packed operations and a byte permute in place of the eight v_alignbit
+      f32x2 acc = {4.0f, 4.0f};
+      acc = __builtin_elementwise_fma(acc, f32x2{2.f, 2.f}, da);
+      acc = __builtin_elementwise_fma(acc, f32x2{2.f, 2.f}, db);
+      acc = __builtin_elementwise_fma(acc, f32x2{2.f, 2.f}, dc);
+      acc = __builtin_elementwise_fma(acc, f32x2{2.f, 2.f}, dd);
+      return __builtin_amdgcn_perm(__float_as_uint(acc.x), __float_as_uint(acc.y), 0x07050301u) & 0x00010001u;
+   }
+#endif
    uint32_t m = 0;
    m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd.y), 31);
    m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd.x), 31);
@@ -489,7 +510,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                count = list_cap + 1;
             }
          }
-#if defined(SPH_ABLATE) && SPH_ABLATE == 9
+#if defined(SPH_ABLATE) && (SPH_ABLATE == 9 || SPH_ABLATE == 12 || SPH_ABLATE == 14)
          mask = 0u;   // timing only: no lists
 #endif
          // append the set bits, ascending, to the lane's neighbour list
@@ -566,10 +587,14 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       }
    }
 
-   // SUM: one pass over the list, in canonical order
+   // SUM: one pass over the list, in canonical order.  TEST only screened: SUM applies the
+   // reference's own test to the reference's own value of every listed pair, leaves a pair that
+   // fails it out of the sum and moves the entries behind it up, so that lists and counts are exactly
+   // the reference's (the write position never passes the read position, and a trip's words are in
+   // registers before its first store).
    const uint32_t* sum_list = list_block + tid;
-   bool screened_wrongly = false;
    const int listed = overflowed ? 0 : count;   // entries to sum from the list
+   int kept = 0;
    for (int j0 = 0; __any(j0 < listed); j0 += DENSITY_UNROLL) {
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
       uint32_t entry[DENSITY_UNROLL];
@@ -595,36 +620,18 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                   if (!UNIT_SCALE) d *= k.sim_scale;
                   density_accumulate(k, mj, d, density);
                }
-            } else {
-               screened_wrongly = true;  // passed the fused screen only: not a neighbour
+               if (kept != j0 + u) my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry[u];
+               kept++;
             }
          }
       }
+#else
+      kept = listed;
 #endif
    }
-   if (__any(screened_wrongly)) {
-      // about one lane in 10^4: rewrite the list without the pairs that are not neighbours (two
-      // entries per word in, two per word out; the write position never passes the read position)
-      if (screened_wrongly) {
-         int kept = 0;
-         for (int j = 0; j < count; j += 2) {
-            const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-               if (j + hf < count) {
-                  const uint32_t entry = hf ? word >> 16 : word & 0xffffu;
-                  const int t = ListEntry<WIDE>::tile(entry);
-                  float dx, dy, dz;
-                  if (dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz) < k.h2) {
-                     my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry;
-                     kept++;
-                  }
-               }
-            }
-         }
-         if (kept & 1) my_entries[(kept >> 1) * (2 * TILE_THREADS) + 1] = (uint16_t)0;
-         count = kept;
-      }
+   if (!overflowed && kept != count) {
+      if (kept & 1) my_entries[(kept >> 1) * (2 * TILE_THREADS) + 1] = (uint16_t)0;
+      count = kept;
    }
    if (live) {
       rho_out[p] = density;

@@ -2,7 +2,8 @@
 (tools/build_variant.sh abl9 WORK -DSPH_ABLATE=9; csrc/full_tiled.h: 1 no SUM, 2 no TEST/append/SUM,
 7 no {v,B} gather, 21 acceleration pass without its pair loop (prologue + epilogue), 22 pair loop
 without the pair arithmetic (lists, gathers, tile reads and distances stay), 9 no append loop at all, 10 append loop without its store, 11 every list store
-to the lane's first word); prints the density and acceleration time of one 4M-particle step for
+to the lane's first word, 12 = 9 with four LDS reads per TEST step instead of six and eight more additions,
+14 = 9 with three LDS reads and four packed operations + a byte permute in place of the eight v_alignbit); prints the density and acceleration time of one 4M-particle step for
 each.  Ablated kernels compute garbage: only the times mean anything, and only for hooks that do
 not change what the later phases have to do (3 / 4 / 5 - no tile load / no row ranges - do, by
 starving TEST of candidates)."""
