@@ -1143,6 +1143,16 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // tile_load).
    float4 buf[BATCH];
    float cbuf[BATCH];
+#if defined(SPH_ABLATE) && SPH_ABLATE == 23
+   // timing only (with the pair loop cut as in 21): no tile
+#pragma unroll
+   for (int r = 0; r < BATCH; r++) {
+      buf[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cbuf[r] = 0.f;
+   }
+   const int total_staged = 0;
+#define total total_staged
+#else
 #pragma unroll
    for (int r = 0; r < BATCH; r++) {
       const int idx = min(tid + r * TILE_THREADS, total - 1);
@@ -1152,6 +1162,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       buf[r] = posm[idx - d];
       cbuf[r] = auxc[idx - d];
    }
+#endif
 
    // Lanes keep their own particle.  (Rounds 1-2 dealt the workgroup's particles to the lanes in
    // order of neighbour count - counting sort through LDS, three barriers - so that a wave's loop
@@ -1203,6 +1214,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       }
    }
    __syncthreads();
+#if defined(SPH_ABLATE) && SPH_ABLATE == 23
+#undef total
+#endif
 
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
@@ -1220,7 +1234,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       first_v = keep < cnt ? cnt - keep : 0;
    }
    if (no_list) cnt = 0;
-#if defined(SPH_ABLATE) && SPH_ABLATE == 21
+#if defined(SPH_ABLATE) && (SPH_ABLATE == 21 || SPH_ABLATE == 23)
    cnt = 0;   // timing only: prologue and epilogue
 #endif
    const int lastw = cnt > 0 ? (cnt - 1) >> 1 : 0;

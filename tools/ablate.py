@@ -1,6 +1,6 @@
 """Kernel time by ablation: build/variants/abl<N>.so are builds with -DSPH_ABLATE=N
 (tools/build_variant.sh abl9 WORK -DSPH_ABLATE=9; csrc/full_tiled.h: 1 no SUM, 2 no TEST/append/SUM,
-7 no {v,B} gather, 21 acceleration pass without its pair loop (prologue + epilogue), 22 pair loop
+7 no {v,B} gather, 21 acceleration pass without its pair loop (prologue + epilogue), 23 = 21 without the tile loads, 22 pair loop
 without the pair arithmetic (lists, gathers, tile reads and distances stay), 9 no append loop at all, 10 append loop without its store, 11 every list store
 to the lane's first word, 12 = 9 with four LDS reads per TEST step instead of six and eight more additions,
 14 = 9 with three LDS reads and four packed operations + a byte permute in place of the eight v_alignbit); prints the density and acceleration time of one 4M-particle step for
