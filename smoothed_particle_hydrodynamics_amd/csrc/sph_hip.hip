@@ -376,6 +376,11 @@ void pick_tile_caps(sph_hip_context* ctx)
    for (int i = 0; i < TSTAT_COUNT; i++) fb[i] = ((volatile int*)ctx->tile_feedback)[i];
    // relative throughput by workgroups per CU (index 1..6), and what an untiled workgroup costs
    // in units of a tiled one
+   // (On the 4M column at rest, with one pass pinned to each level - tools/occupancy_prices.py,
+   // round 3 - the passes lose more than this below 5 per CU: density 1 / 0.97 / 0.87 / 0.74 / 0.54 at
+   // 6 .. 2, acceleration 1 / 0.935 / 0.82 / 0.60 at 5 .. 2.  With those figures the breaking dam,
+   // whose large tiles also hold more work per workgroup, ran 2-10 % slower in five of its sixteen
+   // windows and faster in none: the tables stay as the breaking dam tuned them.)
    static const float density_thr[7] = {0.0f, 0.33f, 0.62f, 0.85f, 0.93f, 0.97f, 1.0f};
    static const float accel_thr[7] = {0.0f, 0.40f, 0.68f, 0.87f, 0.98f, 1.0f, 1.0f};
    caps.cap_density = pick_level(ctx, fb, ctx->density_levels, ctx->density_per_cu,
