@@ -58,11 +58,11 @@ typedef enum sph_hip_status {
  *          the reference's own shipped build may evaluate it (reference CMakeLists.txt:21:
  *          -O3 -ffast-math -funsafe-math-optimizations -mfma), in the ACCELERATION sum only: an
  *          fp32 reciprocal in place of the fp64 quotient of src/sph.cpp:854-856, fused
- *          accumulation, the pressure sum on the hardware square root of the fused d^2, and a
- *          viscous sum (on the reference's stored distance) that leaves out the neighbours whose
- *          weight - the rescale of src/sph.cpp:880-882 applied once per later neighbour - is
- *          below 1e-20.  Neighbour counts AND densities are identical to FULL; accelerations
- *          agree to 1e-4 relative (vector norm; measured 8e-6 on the 4M column); deterministic,
+ *          accumulation, and a viscous sum that leaves out the neighbours whose weight - the
+ *          rescale of src/sph.cpp:880-882 applied once per later neighbour - is below 1e-20;
+ *          both sums on the reference's stored distance.  Neighbour counts AND densities are
+ *          identical to FULL; accelerations agree to 1e-4 relative (vector norm; measured 1.3e-5
+ *          on the 4M column); deterministic,
  *          the same for any route and slab count, not bit-reproducible against the CPU. */
 typedef enum sph_hip_mode {
    SPH_HIP_MODE_REF = 0,

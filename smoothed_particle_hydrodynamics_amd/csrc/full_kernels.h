@@ -139,7 +139,7 @@ __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ 
             float d = sqrtf(d2);
             if (!UNIT_SCALE) d *= k.sim_scale;
             if (FAST) {
-               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, auxc[q]);
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, auxc[q]);
                if (j >= first_v) {
                   const float4 vj = velB[q];
                   accel_pair_fast_viscous(k, s, d, vj.x, vj.y, vj.z, vj.w);

@@ -1034,7 +1034,7 @@ accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const Til
             float dd = sqrt_rn(d2);
             if (!UNIT_SCALE) dd *= k.sim_scale;
             if (FAST) {
-               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, cj[u]);
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, dd, cj[u]);
                if (j0 + u >= first_v) accel_pair_fast_viscous(k, s, dd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
             } else {
                accel_pair<UNIT_SCALE>(k, s, dx, dy, dz, dd, UNIFORM_MASS ? pi.w : pj[u].w, vj[u].x, vj[u].y,
@@ -1262,7 +1262,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #if defined(SPH_ABLATE) && SPH_ABLATE == 22
                s.pgx += pj.x + pj.w;   // timing only: no pair arithmetic
 #else
-               accel_pair_fast_pressure<UNIT_SCALE>(k, s, pi.x - pj.x, pi.y - pj.y, pi.z - pj.z, pj.w);
+               float dx, dy, dz;
+               float d = sqrt_rn(dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz));
+               if (!UNIT_SCALE) d *= k.sim_scale;
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
 #endif
             }
          }
@@ -1358,7 +1361,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                float d = sqrt_rn(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
                if (FAST) {
-                  accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, pj.w);
+                  accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
                   if (jw >= first_v) {
                      const float4 vj = velB[t - D];
                      accel_pair_fast_viscous(k, s, d, vj.x, vj.y, vj.z, vj.w);

@@ -157,29 +157,28 @@ __device__ __forceinline__ void accel_pair(const PairConsts& k, AccelState& s, f
 
 // One neighbour, tolerance mode (see the top of this file): same terms, same place of the viscous
 // rescale; fp32 reciprocal for g = (k2 * r) / (d + 0.01) in place of the fp64 quotient, fused
-// accumulation.  (dx,dy,dz) = r_i - r_j.
-//
-// The two sums take the distance differently.  The PRESSURE sum weights a pair by (h - d)^2: a
-// relative error e of d is an error 2 e d (h - d) of the weight, which vanishes at the rim where
-// h - d cancels - it evaluates d as the hardware square root (1 ulp) of the fused d2
-// (fast_distance: 5 instructions for the correctly rounded root's 18).  The VISCOUS sum weights
-// by h - d and is dominated by its LAST neighbour (every earlier one is rescaled once more,
-// :880-882): an ulp of d there is a relative error of ulp * h / (h - d) in the whole sum - measured
-// 1.5e-3 on accelerations with the fast distance - so it keeps the reference's stored distance,
-// the correctly rounded root of the unfused d2, for the few neighbours it visits (visc_keep).
+// accumulation.  (dx,dy,dz) = r_i - r_j and d = the stored distance exactly as in accel_pair - the
+// correctly rounded root of the unfused d2.  Both sums hang on h - d, a difference of nearly equal
+// numbers for a neighbour near the rim of the kernel, where an ulp of d is a relative error of
+// ulp * d / (h - d) in the pair's term - and a rim term is not a small term: the reference's
+// B_j = p_j / rho_j^2 of a neighbour j whose own density is next to nothing (a particle of the
+// spray: its few neighbours all at its rim) grows like (h - d)^-6, so that the pair's pressure term
+// grows like (h - d)^-4 towards the rim and can be the whole force on i.  A version with the
+// hardware root of the fused d2 in the pressure sum (13 instructions fewer per neighbour, 25 us
+// at 4M) was within 8e-6 on every committed scene and failed seeded random scene 219 - one
+// neighbour at d = 0.998 h_scaled carrying 6809 of a force of 6811 - by 1.09e-4.  A tolerance that
+// holds for any scene needs the reference's own h - d, bit for bit.
+// The two sums are separate functions because the tiled kernel runs them as separate loops: the
+// pressure sum over the whole list (everything it needs of a neighbour is in the tile), the
+// viscous sum over the list's last visc_keep() entries (the only gathers of the pass).  They
+// accumulate into different registers and meet in accel_end, so a route that evaluates both per
+// neighbour in one loop produces the same bits.
 // Bm = m_j * B: the density pass of a FAST context stores the product (neighbor_terms_fast), so no
 // route of the acceleration pass gathers masses.
-__device__ __forceinline__ float fast_distance(float dx, float dy, float dz)
-{
-   return __builtin_amdgcn_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
-}
-
 template <bool UNIT_SCALE>
 __device__ __forceinline__ void accel_pair_fast_pressure(const PairConsts& k, AccelState& s, float dx,
-                                                         float dy, float dz, float Bm)
+                                                         float dy, float dz, float d, float Bm)
 {
-   float d = fast_distance(dx, dy, dz);
-   if (!UNIT_SCALE) d *= k.sim_scale;
    const float rden = __builtin_amdgcn_rcpf(d + 0.01f);
    const float hd = k.hscaled - d;
    // pressure: (k2 * r / den) * (h - d)^2 * (m_j * A) * B
@@ -189,7 +188,7 @@ __device__ __forceinline__ void accel_pair_fast_pressure(const PairConsts& k, Ac
    s.pgz = __builtin_fmaf(dz, f, s.pgz);
 }
 
-// viscosity, rescaled inside the neighbour loop (:880-882); d = the stored distance as in accel_pair
+// viscosity, rescaled inside the neighbour loop (:880-882)
 __device__ __forceinline__ void accel_pair_fast_viscous(const PairConsts& k, AccelState& s, float d,
                                                         float vjx, float vjy, float vjz, float C)
 {
