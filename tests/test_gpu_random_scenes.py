@@ -70,7 +70,12 @@ def test_random_scene(oracle, hiplib, case, mode):
             assert np.array_equal(part.mVelocity, ovel, equal_nan=True), what + "velocity"
 
 
-@pytest.mark.parametrize("case", range(CASES))
+# cases the long soaks singled out (profiles/r3_notes.md, sections 7-8): 219 - one rim neighbour of next
+# to no density carries the whole force; 305 - velocities of 1e-6 and a force that cancels
+SOAK_FINDS = [c for c in (219, 305) if c >= CASES]
+
+
+@pytest.mark.parametrize("case", list(range(CASES)) + SOAK_FINDS)
 def test_random_scene_tolerance_mode(oracle, hiplib, case):
     """the same draws with SPH_HIP_MODE_FULL_FAST, held to tests/test_gpu_full_fast.py's bar (every
     step started from the state the GPU started from)"""
