@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PREHEAT_STEPS = 40             # untimed steps before the warm-up: the device's clocks settle ~15 steps after any idle period
 PAIR_SAMPLE_EVERY = 5          # the density+acceleration pair is timed (two HIP events, ~10 us of
                                # stream time each) on every 5th step of the timed region
 DENSITY_FORCE_BYTES = 64       # algorithmic bytes per particle of the density+force pass
@@ -379,7 +380,7 @@ def run_single(args, S, scenes, torch, local_rank):
         heater = S.SPH(n, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL, device=local_rank)
         heater.setParticles(pos, vel, mass)
         heater.setTiming(S.TIMING_OFF)
-        heater.run(40)
+        heater.run(PREHEAT_STEPS)
         heater.synchronize()
     dt, pair_ms, covered = timed_steps(sph, S, torch, args.warmup, args.steps)
     totals = phase_split(sph, S, lambda: sph.step(), sph.synchronize, sph.setTiming, sph.phaseTotals)
@@ -467,6 +468,12 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
         torch.cuda.synchronize()
         dist.barrier()
 
+    if not args.no_preheat:
+        # the upload left the device idle: PREHEAT_STEPS untimed steps of this very run, before the
+        # W warm-up steps, let its clocks settle (run_single has the story; the column at rest
+        # does not change measurably in that many steps)
+        for _ in range(PREHEAT_STEPS):
+            stepper.step()
     for _ in range(warmup):
         stepper.step()
     fence()
@@ -515,15 +522,16 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
                             mode, "torch.distributed P2P"))}
 
 
-def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup, fast):
+def one_gpu_reference(S, scenes, torch, local_rank, n, box, steps, warmup, fast, preheat=True):
     """The same scene on ONE GPU in a single context (rank 0 only, the other ranks wait): the
-    denominator of the strong-scaling speedup, measured in the same run on the same node."""
+    denominator of the strong-scaling speedup, measured in the same run on the same node (with the
+    same pre-heat as the slab run it is compared with)."""
     p, pos, vel, mass = scenes.dam_break(n, box)
     with S.SPH(n, p, mode=S.MODE_FULL_FAST if fast else S.MODE_FULL, device=local_rank) as sph:
         sph.setParticles(pos, vel, mass)
         del pos, vel, mass
         sph.setTiming(S.TIMING_OFF)
-        sph.run(warmup)
+        sph.run(warmup + (PREHEAT_STEPS if preheat else 0))
         sph.synchronize()
         t0 = time.perf_counter()
         sph.run(steps)
@@ -647,7 +655,8 @@ def main():
             one_ms = None
             if rank == 0:
                 one_ms = one_gpu_reference(S, scenes, torch, local_rank, n, box,
-                                           max(5, args.steps // 2), min(args.warmup, 5), fast)
+                                           max(5, args.steps // 2), min(args.warmup, 5), fast,
+                                           preheat=not args.no_preheat)
             dist.barrier()
             if rank == 0:
                 strong_scaling = {"particles": n, "one_gpu_ms_per_step": one_ms,
@@ -758,10 +767,11 @@ def main():
             line["other_scaling"] = other
         if other_arith is not None:
             line["other_arithmetic"] = other_arith
-        if world == 1 and not args.no_preheat:
-            line["config"]["preheat"] = ("40 untimed steps of the same workload on a scratch context "
-                                         "right before the warm-up (device clocks settle ~15 steps "
-                                         "after any idle period: tools/idle_ramp.py)")
+        if not args.no_preheat:
+            line["config"]["preheat"] = (
+                "%d untimed steps of the same workload %s right before the warm-up (device clocks settle ~15 "
+                "steps after any idle period: tools/idle_ramp.py)" % (
+                    PREHEAT_STEPS, "on a scratch context" if world == 1 else "by every rank's own slab"))
         if world == 1 and not args.no_breaking_dam:
             line["breaking_dam"] = breaking_dam(S, scenes, n, local_rank, fast)
         if world == 1 and args.cpu_sample > 0:
