@@ -755,24 +755,8 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
 #pragma unroll
                   for (int q8 = 0; q8 < 4; q8++) {
                      const int t = t0 + 8 * q8;
-                     if (t < te) {
-                        uint32_t m8 = 0;
-#pragma unroll
-                        for (int hf = 0; hf < 2; hf++) {
-                           const f32x4 X = lds_read4(L.x, t + 4 * hf), Y = lds_read4(L.y, t + 4 * hf),
-                                       Z = lds_read4(L.z, t + 4 * hf);
-                           // the reference's own test on the reference's own value: (dx*dx + dy*dy) + dz*dz < h2
-                           const f32x2 dxa = px - f32x2{X.x, X.y}, dya = py - f32x2{Y.x, Y.y}, dza = pz - f32x2{Z.x, Z.y};
-                           const f32x2 dxb = px - f32x2{X.z, X.w}, dyb = py - f32x2{Y.z, Y.w}, dzb = pz - f32x2{Z.z, Z.w};
-                           const f32x2 da = (dxa * dxa + dya * dya) + dza * dza;
-                           const f32x2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-                           m8 |= (uint32_t)(da.x < k.h2) << (4 * hf + 0);
-                           m8 |= (uint32_t)(da.y < k.h2) << (4 * hf + 1);
-                           m8 |= (uint32_t)(db.x < k.h2) << (4 * hf + 2);
-                           m8 |= (uint32_t)(db.y < k.h2) << (4 * hf + 3);
-                        }
-                        mask |= m8 << (8 * q8);
-                     }
+                     // (the tiled kernel's screen: SUM below confirms on the reference's own value)
+                     if (t < te) mask |= test8(L, t, px, py, pz, k.h2_screen) << (8 * q8);
                   }
                   const int lo_b = ts - t0, hi_b = te - t0;
                   if (lo_b > 0) mask &= ~0u << lo_b;
@@ -799,22 +783,46 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                }
             }
             // SUM of what this chunk added, in list order (a lane reads what it has written: behind
-            // a barrier, as the tiled kernel's SUM is behind one)
+            // a barrier, as the tiled kernel's SUM is behind one).  TEST only screened: a pair that
+            // fails the reference's own test is left out of the sum and of the list, the entries
+            // behind it move up (the write position never passes the read position; a trip's
+            // words are in registers before its first store).
             __syncthreads();
-            if (count <= list_cap) {
-               for (int j = first_new; j < count; j++) {
-                  const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
-                  const uint32_t entry = (j & 1) ? word >> 16 : word & 0xffffu;
-                  const int t = ListEntry<WIDE>::tile(entry) - D - c0;
-                  float mj = pi.w;
-                  if (!UNIFORM_MASS) mj = posm[c0 + t].w;
-                  float dx, dy, dz;
-                  const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-                  {
-                     float d = sqrt_rn(d2);
-                     if (!UNIT_SCALE) d *= k.sim_scale;
-                     density_accumulate(k, mj, d, density);
+            if (__any(count <= list_cap && first_new < count)) {
+               const int listed = count <= list_cap ? count : first_new;   // (an overflowed lane sums nothing)
+               int kept = first_new;
+               constexpr int CU = 4;
+               for (int j0 = first_new; __any(j0 < listed); j0 += CU) {
+                  uint32_t entry[CU];
+#pragma unroll
+                  for (int u = 0; u < CU; u++) {
+                     const int j = min(j0 + u, listed > first_new ? listed - 1 : first_new);
+                     const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
+                     entry[u] = (j & 1) ? word >> 16 : word & 0xffffu;
                   }
+#pragma unroll
+                  for (int u = 0; u < CU; u++) {
+                     if (j0 + u < listed) {
+                        const int t = ListEntry<WIDE>::tile(entry[u]) - D - c0;
+                        float mj = pi.w;
+                        if (!UNIFORM_MASS) mj = posm[c0 + t].w;
+                        float dx, dy, dz;
+                        const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+                        if (d2 < k.h2) {
+                           float d = sqrt_rn(d2);
+                           if (!UNIT_SCALE) d *= k.sim_scale;
+                           density_accumulate(k, mj, d, density);
+                           if (kept != j0 + u)
+                              my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry[u];
+                           kept++;
+                        }
+                     }
+                  }
+               }
+               if (count <= list_cap && kept != count) {     // the append position follows the list's end
+                  count = kept;
+                  half = (uint32_t)((count >> 1) * (2 * TILE_THREADS) + (count & 1));
+                  step = (count & 1) ? 2 * TILE_THREADS - 1 : 1;
                }
             }
          }
