@@ -25,17 +25,44 @@ def library_path():
     return os.environ.get("SPH_HIP_LIBRARY") or os.path.join(HERE, "libsph_hip.so")
 
 
+def _code_only(text):
+    """C++ source without comments, trailing blanks and empty lines (string and character literals
+    kept as they are): what source_hash() hashes, so that a reworded comment does not orphan a
+    committed profile."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    lines = (line.rstrip() for line in "".join(out).split("\n"))
+    return "\n".join(line for line in lines if line)
+
+
 def source_hash():
-    """sha256 (first 16 hex digits) over the kernel sources and the C header: what a committed
-    counter profile (profiles/) is stamped with, so that bench.py can tell whether it still
-    describes the code being run."""
+    """sha256 (first 16 hex digits) over the kernel sources and the C header, comments excluded:
+    what a committed counter profile (profiles/) is stamped with, so that bench.py can tell whether
+    it still describes the code being run."""
     import hashlib
     h = hashlib.sha256()
     for name in sorted(SOURCES + HEADERS):
         path = os.path.normpath(os.path.join(CSRC, name))
         h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
-            h.update(f.read())
+        with open(path, "r", encoding="utf-8", errors="replace") as f:
+            h.update(_code_only(f.read()).encode())
     return h.hexdigest()[:16]
 
 

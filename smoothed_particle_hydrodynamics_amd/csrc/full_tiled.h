@@ -320,7 +320,7 @@ __device__ __forceinline__ void tile_load(const float4* __restrict__ posm, const
 // sign.  Near the threshold the two evaluations are within 2.5 + 1.5 ulp(h2) < 5e-7 * h2 of the
 // true value, so every neighbour the exact test accepts passes the screen; a candidate that passes it wrongly (about one in 10^6) is
 // caught by SUM, which needs the exact value of every listed pair for the distance anyway: it
-// leaves the pair out of the sum, and the lane then rewrites its list without it, so neighbour
+// leaves the pair out of the sum and out of the list (the entries behind it move up), so neighbour
 // lists and counts are exactly the reference's.
 
 // d2 - h2_screen of two candidates at once, three fused multiply-adds: for screening only (its
@@ -653,9 +653,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // has to search again the same way.  This kernel is launched BEFORE the tiled one when the last
 // step reported many of them, and stages the candidates through the same LDS tile in pieces:
 // segment after segment (ascending = canonical order), chunk after chunk of at most tile_cap
-// sorted positions.  Per chunk: TEST + append + SUM exactly as the tiled kernel does them, with
-// the reference's unfused distance test applied directly (no screening: two packed operations
-// more per candidate pair, no list rewrite).  List entries are the indices of the workgroup's
+// sorted positions.  Per chunk: TEST (the same screen) + append + SUM (confirming, four entries
+// per trip) as the tiled kernel does them.  List entries are the indices of the workgroup's
 // VIRTUAL tile (the layout its descriptor describes, wherever it would have been): the
 // acceleration pass - for which the tile is too large as well - walks them with operands from
 // global memory (accel_from_lists).  Same neighbours, same order, same arithmetic: same bits.

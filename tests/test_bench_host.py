@@ -119,3 +119,13 @@ def test_control_plane_never_uses_the_exchange_group(bench, monkeypatch):
     main_src = inspect.getsource(bench.main)
     assert 'init_process_group("gloo"' in main_src and 'new_group(backend="nccl")' in main_src
     assert main_src.index("preflight(rank, world)") < main_src.index("torch.cuda.set_device")
+
+
+def test_source_hash_ignores_comments():
+    """a reworded comment must not orphan a committed profile; a changed token must"""
+    from smoothed_particle_hydrodynamics_amd.build import _code_only
+    a = 'int a = 1; // one\n/* block\n   comment */ int b = 2;\nconst char* s = "// kept /* kept */";\n\n'
+    b = 'int a = 1; // another wording\nint b = 2;   \nconst char* s = "// kept /* kept */";\n'
+    assert _code_only(a).split() == _code_only(b).split()
+    assert '"// kept /* kept */"' in _code_only(a)
+    assert _code_only(a) != _code_only(a.replace("= 2", "= 3"))
