@@ -1050,6 +1050,7 @@ accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const Til
          }
       }
    }
+   if (FAST) accel_fast_finish(s);
    return accel_end<UNIT_SCALE>(k, s);
 }
 
@@ -1250,6 +1251,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
    for (int u = 1; u < ACCEL_UNROLL / 2; u++) next_word[u] = u <= lastw ? next_word[u] : next_word[u - 1];
    if constexpr (FAST) {
+      const int self_tile = live ? p + L.desc.D[4] : 0;   // (the lane's own entry of the tile)
       // The pressure sum over the whole list: everything it needs of a neighbour is in the tile
       // ({x, y, z, m B}), no gather.  The list entries of the NEXT trip are requested before this
       // trip's arithmetic.  Lanes past their count re-read their last entry (result unused).
@@ -1262,20 +1264,28 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             const int w = (j0 + ACCEL_UNROLL) / 2 + u;
             next_word[u] = my_list[(w < lastw ? w : lastw) * TILE_THREADS];
          }
+         // (the trip's roots taken together - sqrt_rn_batch - and no branch on j0 + u < cnt: a lane
+         // past its count takes ITSELF as the neighbour with m B = 0 - r = 0 and a factor of zero:
+         // the sum does not move - so that the eight pairs of a trip are one basic block)
+         float dx[ACCEL_UNROLL], dy[ACCEL_UNROLL], dz[ACCEL_UNROLL], dd[ACCEL_UNROLL], bm[ACCEL_UNROLL];
 #pragma unroll
          for (int u = 0; u < ACCEL_UNROLL; u++) {
-            if (j0 + u < cnt) {
-               const float4 pj = xyzc[ListEntry<WIDE>::tile(entry[u])];
-#if defined(SPH_ABLATE) && SPH_ABLATE == 22
-               s.pgx += pj.x + pj.w;   // timing only: no pair arithmetic
-#else
-               float dx, dy, dz;
-               float d = sqrt_rn(dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx, dy, dz));
-               if (!UNIT_SCALE) d *= k.sim_scale;
-               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, d, pj.w);
-#endif
-            }
+            const bool valid = j0 + u < cnt;
+            const float4 pj = xyzc[valid ? ListEntry<WIDE>::tile(entry[u]) : self_tile];
+            dd[u] = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx[u], dy[u], dz[u]);
+            bm[u] = valid ? pj.w : 0.0f;
          }
+#if defined(SPH_ABLATE) && SPH_ABLATE == 22
+#pragma unroll
+         for (int u = 0; u < ACCEL_UNROLL; u++) s.pgx += dd[u] + bm[u];   // timing only: no pair arithmetic
+#else
+         sqrt_rn_batch(dd);
+#pragma unroll
+         for (int u = 0; u < ACCEL_UNROLL; u++) {
+            if (!UNIT_SCALE) dd[u] *= k.sim_scale;
+            accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx[u], dy[u], dz[u], dd[u], bm[u]);
+         }
+#endif
       }
       // The viscous sum over the list's last visc_keep() entries (ascending, as everywhere): the
       // only neighbours whose {v, C} is gathered, with the reference's stored distance.
@@ -1384,6 +1394,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          }
       }
    }
+   if (FAST) accel_fast_finish(s);
    const float4 a_i = accel_end<UNIT_SCALE>(k, s);
    if (live) acc[p] = a_i;
    if (fs.on) fused_integrate<UNIT_SCALE>(fs, k, g, p, live, pi, a_i, wg);

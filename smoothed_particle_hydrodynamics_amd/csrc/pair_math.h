@@ -90,7 +90,7 @@ __device__ __forceinline__ float2 neighbor_terms_fast(const PairConsts& k, float
 
 struct AccelState {
    float rhoi_inv, pi_div_rhoi2, visc_scale;
-   float k2a;   // FAST: kernel2 * A (* sim_scale): what multiplies r / den in the pressure term
+   float k2s;   // FAST: kernel2 * sim_scale * 2^-64: what multiplies r / den in the pressure term (FAST_PG_SCALE)
    float rx, ry, rz, vx, vy, vz;
    float pgx, pgy, pgz, vtx, vty, vtz;
 };
@@ -104,7 +104,7 @@ __device__ __forceinline__ void accel_begin(const PairConsts& k, AccelState& s, 
    const float rhoi_inv2 = s.rhoi_inv * s.rhoi_inv;
    s.pi_div_rhoi2 = pi * rhoi_inv2;
    s.visc_scale = k.viscosity * s.rhoi_inv;
-   s.k2a = k.kernel2 * s.pi_div_rhoi2 * k.sim_scale;
+   s.k2s = (k.kernel2 * k.sim_scale) * 0x1p-64f;
    s.rx = posm.x; s.ry = posm.y; s.rz = posm.z;
    s.vx = velp.x; s.vy = velp.y; s.vz = velp.z;
    s.pgx = s.pgy = s.pgz = 0.0f;
@@ -179,13 +179,31 @@ template <bool UNIT_SCALE>
 __device__ __forceinline__ void accel_pair_fast_pressure(const PairConsts& k, AccelState& s, float dx,
                                                          float dy, float dz, float d, float Bm)
 {
-   const float rden = __builtin_amdgcn_rcpf(d + 0.01f);
    const float hd = k.hscaled - d;
-   // pressure: (k2 * r / den) * (h - d)^2 * (m_j * A) * B
-   const float f = ((hd * hd) * rden) * (s.k2a * Bm);
+   // pressure: (k2 * r / den) * ((h - d)^2 * ((m_j * A) * B)).  Where the numbers stop being finite
+   // the grouping matters: B of a neighbour with next to no density is ~1e29.  A first version
+   // multiplied (k2 A) by (m B) before (h - d)^2, overflowed five orders of magnitude before the
+   // reference does and met 0 * inf where the reference's clamp of an overflowed |a|^2 returns zeros
+   // (seeded random scene 1751 of the soak).  Now: c = (h - d)^2 * (A * (m B)) as the reference
+   // forms it - it overflows when the reference's does - and the scalar k2 / den it is multiplied
+   // with carries a factor 2^-64 that accel_fast_finish() takes out of the finished sum: the
+   // per-pair factor f cannot overflow unless c has, whatever the pair's r is, and a sum the
+   // reference overflows overflows here when the factor is taken out (5 multiplications and 3 fused
+   // multiply-adds per neighbour; the reference's own grouping, g = k2 r / den per component, costs 7 + 3
+   // and measured 22 us more at 4M).
+   const float c = (hd * hd) * (s.pi_div_rhoi2 * Bm);
+   const float f = c * (s.k2s * __builtin_amdgcn_rcpf(d + 0.01f));
    s.pgx = __builtin_fmaf(dx, f, s.pgx);
    s.pgy = __builtin_fmaf(dy, f, s.pgy);
    s.pgz = __builtin_fmaf(dz, f, s.pgz);
+}
+
+// the pressure sum of a FAST context is accumulated times 2^-64 (accel_pair_fast_pressure): before accel_end
+__device__ __forceinline__ void accel_fast_finish(AccelState& s)
+{
+   s.pgx *= 0x1p64f;
+   s.pgy *= 0x1p64f;
+   s.pgz *= 0x1p64f;
 }
 
 // viscosity, rescaled inside the neighbour loop (:880-882)

@@ -306,8 +306,43 @@ __device__ __forceinline__ float sqrt_rn(float x)
    const float d = __builtin_fmaf(-g, g, x);
    return __builtin_fmaf(d, h, g);
 }
+
+// The same root for N values at once, with ONE uniform branch for the lot: a pair loop that takes
+// the roots of the N neighbours of a trip one by one gets a scalar branch per neighbour from
+// sqrt_rn's test for tiny arguments, which fences every neighbour's dependent chain (reciprocal
+// square root, three fused steps, the pair arithmetic behind them) off from the next one's; taken
+// together the N chains are one basic block and overlap.  Same values as sqrt_rn, bit for bit.
+template <int N>
+__device__ __forceinline__ void sqrt_rn_batch(float (&x)[N])
+{
+   bool tiny = false;
+#pragma unroll
+   for (int u = 0; u < N; u++) tiny |= __float_as_uint(x[u]) - 1u < 0x0c7fffffu;
+   if (__builtin_expect(__any(tiny), 0)) {
+#pragma unroll
+      for (int u = 0; u < N; u++) x[u] = sqrtf(x[u]);
+      return;
+   }
+#pragma unroll
+   for (int u = 0; u < N; u++) {
+      const float y = __builtin_amdgcn_rsqf(fmaxf(x[u], 1.17549435e-38f));
+      float g = x[u] * y;
+      float h = 0.5f * y;
+      const float r = __builtin_fmaf(-h, g, 0.5f);
+      g = __builtin_fmaf(g, r, g);
+      h = __builtin_fmaf(h, r, h);
+      const float d = __builtin_fmaf(-g, g, x[u]);
+      x[u] = __builtin_fmaf(d, h, g);
+   }
+}
 #else
 __device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+template <int N>
+__device__ __forceinline__ void sqrt_rn_batch(float (&x)[N])
+{
+#pragma unroll
+   for (int u = 0; u < N; u++) x[u] = sqrtf(x[u]);
+}
 #endif
 
 // fp32 squared distance with the reference's association: (dx*dx + dy*dy) + dz*dz, no FMA
