@@ -61,7 +61,7 @@ typedef enum sph_hip_status {
  *          accumulation, and a viscous sum that leaves out the neighbours whose weight - the
  *          rescale of src/sph.cpp:880-882 applied once per later neighbour - is below 1e-20;
  *          both sums on the reference's stored distance.  Neighbour counts AND densities are
- *          identical to FULL; accelerations agree to 1e-4 relative (vector norm; measured 1.3e-5
+ *          identical to FULL; accelerations agree to 1e-4 relative (vector norm; measured 6e-6
  *          on the 4M column); deterministic,
  *          the same for any route and slab count, not bit-reproducible against the CPU. */
 typedef enum sph_hip_mode {
