@@ -109,3 +109,29 @@ def test_random_scene_tolerance_mode(oracle, hiplib, case):
             ok = np.repeat(finite, 3)
             check_fast_velocity(np.where(ok, part.mVelocity, 0), np.where(ok, ovel, 0), allowed, p.time_step, what)
             cur_pos, cur_vel = part.mPosition.copy(), part.mVelocity.copy()
+
+
+@pytest.mark.parametrize("env", [{"SPH_HIP_UNTILED": "1"}, {"SPH_HIP_TILE_CAP": "512"}, {"SPH_HIP_LIST_CAP": "30"}],
+                         ids=["untiled", "tile-cap-512", "list-cap-30"])
+@pytest.mark.parametrize("case", range(CASES))
+def test_random_scene_tolerance_mode_any_route(hiplib, case, env, monkeypatch):
+    """the tolerance-mode arithmetic is written out operation by operation: the routes that do not
+    split their neighbour loop (untiled, give-up workgroups, the walk of a particle without a list)
+    produce the bits of the tiled one - which is what makes a slab's ghosts agree with their owner"""
+    import smoothed_particle_hydrodynamics_amd as S
+    p, pos, vel, mass = draw(case)
+    out = []
+    for e in ({}, env):
+        for k in ("SPH_HIP_UNTILED", "SPH_HIP_TILE_CAP", "SPH_HIP_LIST_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST) as sph:
+            sph.setParticles(pos, vel, mass)
+            sph.step()
+            sph.step()
+            part = sph.getParticles()
+            out.append({k: getattr(part, k).copy() for k in ("mPosition", "mVelocity", "mDensity",
+                                                            "mAcceleration", "mNeighborCount")})
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), "case %d: %s" % (case, k)
