@@ -141,6 +141,13 @@ def test_fast_edge_cases(oracle, hiplib):
     run_fast(oracle, p, np.ascontiguousarray(pos.reshape(-1)), vel, mass, steps=2)
 
 
+def test_fast_distances_below_the_fast_root_s_range(oracle, hiplib):
+    """squared distances below 2^-102: the batched root of the pressure loop takes its other path"""
+    from test_gpu_full_mode import _tiny_distance_scene
+    p, pos, vel, mass = _tiny_distance_scene()
+    run_fast(oracle, p, pos, vel, mass, steps=2)
+
+
 @pytest.mark.parametrize("n", [1, 2, 64, 257])
 def test_fast_tiny_counts(oracle, hiplib, n):
     from smoothed_particle_hydrodynamics_amd import scenes

@@ -102,6 +102,26 @@ def test_full_tiny_counts(oracle, hiplib, n):
     run_case(oracle, p, pos, vel, mass, steps=2)
 
 
+def _tiny_distance_scene():
+    """300 particles of a dense block, 40 of them moved to within 1e-20 .. 1e-17 of each other next
+    to the box's origin: squared distances between 2^-150 and 2^-102, where the pair loops' square
+    root takes its other path (sqrt_rn / sqrt_rn_batch: csrc/sph_device.h) - and zero velocities, so
+    that nothing moves them apart before the second step"""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(300, lo=(0.0, 0.0, 0.0), hi=(0.3, 0.3, 0.3), seed=3, speed=0.0)
+    pos = pos.reshape(-1, 3)
+    k = np.arange(40, dtype=np.float32)
+    pos[:40, 0] = np.float32(1e-20) * (1 + k * k)
+    pos[:40, 1] = np.float32(3e-21) * (1 + 7 * k)
+    pos[:40, 2] = np.float32(5e-19) * (k % 5)
+    return p, np.ascontiguousarray(pos.reshape(-1)), np.zeros_like(vel), mass
+
+
+def test_full_distances_below_the_fast_root_s_range(oracle, hiplib):
+    p, pos, vel, mass = _tiny_distance_scene()
+    run_case(oracle, p, pos, vel, mass, steps=2)
+
+
 def test_full_phase_calls_equal_step(oracle, hiplib):
     """the five protected methods called one by one == step()"""
     import smoothed_particle_hydrodynamics_amd as S
