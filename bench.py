@@ -182,6 +182,58 @@ def cpu_baseline(n_sample, steps, n_total):
     }
 
 
+def reference_pair_functions(n_sample, n_total, passes=24):
+    """The compiled reference's OWN computeDensity + computeAcceleration (src/sph.cpp:721-766, 778-934;
+    oracle/_ref/libsphref.so, one thread like the original) on complete neighbour lists in the
+    canonical order, for a slice of the same dam-break column - the pair functions of the pass
+    `roofline` prices, timed where `cpu_baseline` times the port's whole step.  The lists are built
+    (untimed) by the port, the reference's results are checked against the port's bit for bit.
+    None when the reference build is not present."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from smoothed_particle_hydrodynamics_amd import scenes
+    frac = n_sample / float(n_total)
+    # (the scene first: it loads libsph_hip.so and with it torch's ROCm runtime, which must be in the
+    # process before libsphref.so - Qt5Core from /opt/conda, static libstdc++ - is)
+    p, pos, vel, mass = scenes.dam_break(n_sample, box=(1.0, 1.0, frac))
+    if not orc.reference_available():
+        return None
+    op = orc.OracleParams()
+    C.memmove(C.byref(op), C.byref(p), C.sizeof(op))
+    port = orc.Oracle()
+    cap = 96
+    nb, nd, cnt, worst = port.full_build_lists(op, pos, cap)
+    if worst > cap:
+        cap = int(worst)
+        nb, nd, cnt, worst = port.full_build_lists(op, pos, cap)
+    ref = orc.Reference()
+    ref.configure(op, n_sample)
+    ref.set_state(pos, vel, mass)
+    ref.set_lists(cap, nb, nd, cnt)
+    ref.compute_density()                       # untimed: first touch
+    ref.compute_acceleration()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        ref.compute_density()
+    t1 = time.perf_counter()
+    for _ in range(passes):
+        ref.compute_acceleration()
+    t2 = time.perf_counter()
+    got = ref.get_state()
+    _, cs, ci = port.full_cells(op, pos)
+    rho, _ = port.full_density(op, pos, mass, cs, ci)
+    acc = port.full_accel(op, pos, vel, mass, rho, cs, ci)
+    same = bool(np.array_equal(got["rho"], rho) and np.array_equal(got["acc"], acc))
+    dens, accel = (t1 - t0) / passes, (t2 - t1) / passes
+    return {"value": n_sample / (dens + accel) / 1e6, "unit": "Mparticle-passes/s (density + acceleration)",
+            "cores": 1, "kind": "reference",
+            "ms_density": dens * 1e3, "ms_acceleration": accel * 1e3,
+            "equals_port_bit_for_bit": same,
+            "sample": "%d-particle slice of the same column, %.1f neighbours/particle, complete canonical lists "
+                      "(built untimed by the port), %d passes of SPH::computeDensity + SPH::computeAcceleration "
+                      "of the compiled src/sph.cpp, %.1f s" % (n_sample, float(cnt.mean()), passes, t2 - t0)}
+
+
 def reference_scene(S, steps=8, n=32768):
     """The reference's own compiled src/sph.cpp (oracle/_ref, built where /root/reference exists
     and shipped as a .so) timed on this box on ITS default scene - srand(42) sphere, 32 768
@@ -393,6 +445,7 @@ def run_single(args, S, scenes, torch, local_rank):
     # a side record, never `value`
     sph.setArithmetic(S.ARITH_EXACT if fast else S.ARITH_FAST)
     odt, opair, ocovered = timed_steps(sph, S, torch, args.warmup, args.steps)
+    parity = arithmetic_parity(sph, S, mass)
     other = {"arithmetic": "exact" if fast else "fast", "value": n * args.steps / odt / 1e6,
              "unit": "Mparticle-steps/s", "ms_per_step": odt / args.steps * 1e3,
              "ms_per_launch_pair": opair, "launch_pairs_timed": ocovered,
@@ -402,8 +455,48 @@ def run_single(args, S, scenes, torch, local_rank):
     sph.close()
     if heater is not None:
         heater.close()
-    return p, dt, totals, covered, n, nb_mean, "1 GPU", other
+    return p, dt, totals, covered, n, nb_mean, "1 GPU", other, parity
 
+
+def arithmetic_parity(sph, S, mass):
+    """The line's own proof of the tolerance-mode arithmetic, GPU against GPU, outside every timed
+    region: ONE step from the state the timed steps ended in, once with the bit-exact arithmetic
+    (which the test suite holds to the CPU oracle bit for bit, tests/test_gpu_full_size.py) and once
+    with the tolerance-mode one, from the same positions and velocities.  Neighbour counts and
+    densities must be identical; the acceleration of EVERY particle within the north star's 1e-4
+    relative (|a - a_exact| <= 1e-4 * max(|a|, |a_exact|)): `beyond_1e-4` counts those that are not."""
+    part = sph.getParticles()
+    pos, vel = part.mPosition.copy(), part.mVelocity.copy()
+    res = {}
+    for name, arith in (("exact", S.ARITH_EXACT), ("fast", S.ARITH_FAST)):
+        sph.setArithmetic(arith)
+        sph.setParticles(pos, vel, mass)
+        sph.step()
+        assert sph.getArithmetic() == arith
+        q = sph.getParticles()
+        res[name] = (q.mAcceleration.astype(np.float64).reshape(-1, 3), q.mDensity.copy(), q.mNeighborCount.copy())
+    a, b = res["fast"][0], res["exact"][0]
+    den = np.maximum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1))
+    den[den == 0] = 1.0
+    rel = np.linalg.norm(a - b, axis=1) / den
+    return {"max_rel": float(rel.max()), "beyond_1e-4": int((rel > 1e-4).sum()),
+            "p9999_rel": float(np.quantile(rel, 0.9999)),
+            "counts_equal": bool(np.array_equal(res["fast"][2], res["exact"][2])),
+            "density_equal": bool(np.array_equal(res["fast"][1], res["exact"][1])),
+            "particles": int(rel.size),
+            "note": "one step from the state the timed steps ended in, tolerance-mode arithmetic vs the "
+                    "bit-exact one on the same context (GPU vs GPU, outside the timed regions); the "
+                    "bit-exact arithmetic is held to the CPU oracle bit for bit by tests/test_gpu_full_size.py"}
+
+
+PARITY_BAR = {
+    "fast": "neighbour counts and densities identical to the CPU reference's; acceleration of EVERY particle "
+            "within 1e-4 relative (vector norm) - asserted without escape clauses on every BASELINE "
+            "configuration (tests/test_gpu_full_fast.py, test_gpu_full_size.py, test_gpu_c4_c5.py); see "
+            "`parity` in this line for this run's own exact-vs-fast check",
+    "exact": "every per-particle output bit-identical to the CPU oracle (tests/test_gpu_full_mode.py, "
+             "test_gpu_full_size.py, test_gpu_c4_c5.py)",
+}
 
 C3_PARTICLES = 4 * 1024 * 1024      # BASELINE configs[2]
 C4_PARTICLES = 16 * 1024 * 1024     # BASELINE configs[3]: strong scaling over the node
@@ -512,6 +605,8 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
     return {"params": p, "dt": dt, "totals": totals, "covered": covered, "n": n,
             "n_rank": st["owned"], "neighbors_mean": nb_mean, "steps": steps, "box": box,
             "ranks": dist.get_world_size(),
+            "rebalances_in_run": int(getattr(stepper, "rebalances", 0)),
+            "message_growths_in_run": int(getattr(stepper, "message_growths", 0)),
             "halo_message_bytes": SL.message_bytes(msg_records),
             "halo_message_bytes_allocated": SL.message_bytes(msg_allocated),
             "parallelism": "z-slab x%d, RCCL halo (%s)" % (
@@ -623,6 +718,7 @@ def main():
         S.build_library()
     strong_scaling = None
     other_arith = None
+    parity = None
     fast = args.arithmetic == "fast"
     if world > 1:
         import torch.distributed as dist
@@ -649,7 +745,9 @@ def main():
         p, dt, totals, covered = r["params"], r["dt"], r["totals"], r["covered"]
         n_rank, nb_mean, par, ranks = r["n_rank"], r["neighbors_mean"], r["parallelism"], r["ranks"]
         halo = {"bytes_per_message": r["halo_message_bytes"],
-                "bytes_allocated": r["halo_message_bytes_allocated"]}
+                "bytes_allocated": r["halo_message_bytes_allocated"],
+                # (a rebalance replaces the slab context: a timed region that contained one is recognisable)
+                "rebalances_in_run": r["rebalances_in_run"], "message_growths_in_run": r["message_growths_in_run"]}
         if args.scaling == "strong" and not args.no_one_gpu_reference:
             # the same scene on one GPU, same run: what the N-GPU time is a speedup OF
             one_ms = None
@@ -684,8 +782,8 @@ def main():
     else:
         n = args.particles or C3_PARTICLES
         args.particles = n
-        p, dt, totals, covered, n_rank, nb_mean, par, other_arith = run_single(args, S, scenes, torch,
-                                                                               local_rank)
+        p, dt, totals, covered, n_rank, nb_mean, par, other_arith, parity = run_single(args, S, scenes, torch,
+                                                                                       local_rank)
         box, other, ranks = (1.0, 1.0, 1.0), None, 1
 
     if rank == 0:
@@ -694,6 +792,7 @@ def main():
         achieved = DENSITY_FORCE_BYTES * n_rank / (df_ms * 1e-3) / 1e9
         prof, prof_note = kernel_counters(n, args.arithmetic) if world == 1 else (None, "1-GPU profile only")
         valu = valu_issue(prof, df_ms) if prof is not None else None
+        traffic = prof["density_plus_acceleration_hbm_bytes"] if prof else None
         scaling = args.scaling if world > 1 else "weak"
         line = {
             "metric": "Mparticle-steps/sec (whole node), dam-break" + (
@@ -711,6 +810,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "arithmetic": args.arithmetic,
+            "parity_bar": PARITY_BAR[args.arithmetic],
             "config": {
                 "workload": "dam-break %d particles%s in a %gx%gx%g box, fp32, FULL neighbour "
                             "mode, cell grid rebuilt every step, %s" % (
@@ -741,9 +842,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": prof["density_plus_acceleration_hbm_bytes"] if prof else None,
+                "traffic": traffic,
                 "traffic_unit": "bytes per launch pair",
                 "traffic_source": prof_note,
+                # the counter bytes as a rate against the chip's peak (what rocprof says the pair moves
+                # through HBM per second of ITS OWN duration), and against the algorithmic bytes
+                "traffic_gbs": None if traffic is None else traffic / (df_ms * 1e-3) / 1e9,
+                "traffic_frac": None if traffic is None else traffic / (df_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic_over_algorithmic": None if traffic is None else traffic / float(DENSITY_FORCE_BYTES * n_rank),
                 "valu": valu,
                 "bytes_per_particle": DENSITY_FORCE_BYTES,
                 "particles_per_launch": n_rank,
@@ -767,6 +873,10 @@ def main():
             line["other_scaling"] = other
         if other_arith is not None:
             line["other_arithmetic"] = other_arith
+            # the bit-exact arithmetic's throughput, as prominent as `value` (same run, same state)
+            line["value_%s_arithmetic" % other_arith["arithmetic"]] = other_arith["value"]
+        if parity is not None:
+            line["parity"] = parity
         if not args.no_preheat:
             line["config"]["preheat"] = (
                 "%d untimed steps of the same workload %s right before the warm-up (device clocks settle ~15 "
@@ -776,6 +886,9 @@ def main():
             line["breaking_dam"] = breaking_dam(S, scenes, n, local_rank, fast)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.cpu_steps, n)
+            pair_fn = reference_pair_functions(min(args.cpu_sample, n), n)
+            if pair_fn is not None:
+                line["cpu_baseline"]["reference_pair_functions"] = pair_fn
             ref_scene = reference_scene(S)
             if ref_scene is not None:
                 line["reference_scene"] = ref_scene

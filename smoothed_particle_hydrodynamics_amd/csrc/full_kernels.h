@@ -152,7 +152,7 @@ __device__ __forceinline__ void accel_untiled(int p, const float4* __restrict__ 
          }
       }
    }
-   if (FAST) accel_fast_finish(s);
+   if (FAST) accel_fast_finish(k, s);
    acc[p] = accel_end<UNIT_SCALE>(k, s);
 }
 

@@ -1050,7 +1050,7 @@ accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const Til
          }
       }
    }
-   if (FAST) accel_fast_finish(s);
+   if (FAST) accel_fast_finish(k, s);
    return accel_end<UNIT_SCALE>(k, s);
 }
 
@@ -1122,7 +1122,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       } else if (mine) {
          accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
       }
-      if (fs.on) {
+      // (a two-part launch walks the give-up list in BOTH parts: only the part that owns the listed
+      // workgroup integrates it and writes its energy partial sums - the other part's zeros would race
+      // with them on the unordered streams; workgroup-uniform, so the barriers inside stay legal)
+      if (fs.on && accel_part_has(part, g0, meta)) {
          float4 gx = make_float4(0.f, 0.f, 0.f, 0.f), ga = gx;
          if (mine) {
             gx = posm[gp];
@@ -1255,6 +1258,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       // The pressure sum over the whole list: everything it needs of a neighbour is in the tile
       // ({x, y, z, m B}), no gather.  The list entries of the NEXT trip are requested before this
       // trip's arithmetic.  Lanes past their count re-read their last entry (result unused).
+      // (A lane past its count relies on 0 * A = 0.  A = p_i * rhoiInv^2 is not finite when p_i is a
+      // positive subnormal (1 / p_i = inf), and 0 * inf would poison a sum the list-walking routes leave
+      // untouched: a wave holding such a lane - never seen outside a test - selects the factor instead.)
+      const bool odd_lane = __any(!__builtin_isfinite(s.pi_div_rhoi2));
       for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
 #pragma unroll
          for (int u = 0; u < ACCEL_UNROLL; u++)
@@ -1280,10 +1287,18 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          for (int u = 0; u < ACCEL_UNROLL; u++) s.pgx += dd[u] + bm[u];   // timing only: no pair arithmetic
 #else
          sqrt_rn_batch(dd);
+         if (!odd_lane) {
 #pragma unroll
-         for (int u = 0; u < ACCEL_UNROLL; u++) {
-            if (!UNIT_SCALE) dd[u] *= k.sim_scale;
-            accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx[u], dy[u], dz[u], dd[u], bm[u]);
+            for (int u = 0; u < ACCEL_UNROLL; u++) {
+               if (!UNIT_SCALE) dd[u] *= k.sim_scale;
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx[u], dy[u], dz[u], dd[u], bm[u]);
+            }
+         } else {
+#pragma unroll
+            for (int u = 0; u < ACCEL_UNROLL; u++) {
+               if (!UNIT_SCALE) dd[u] *= k.sim_scale;
+               if (j0 + u < cnt) accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx[u], dy[u], dz[u], dd[u], bm[u]);
+            }
          }
 #endif
       }
@@ -1394,7 +1409,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          }
       }
    }
-   if (FAST) accel_fast_finish(s);
+   if (FAST) accel_fast_finish(k, s);
    const float4 a_i = accel_end<UNIT_SCALE>(k, s);
    if (live) acc[p] = a_i;
    if (fs.on) fused_integrate<UNIT_SCALE>(fs, k, g, p, live, pi, a_i, wg);

@@ -90,7 +90,7 @@ __device__ __forceinline__ float2 neighbor_terms_fast(const PairConsts& k, float
 
 struct AccelState {
    float rhoi_inv, pi_div_rhoi2, visc_scale;
-   float k2s;   // FAST: kernel2 * sim_scale * 2^-64: what multiplies r / den in the pressure term (FAST_PG_SCALE)
+   float k2s;   // FAST: kernel2 * sim_scale * 2^-shift (PairConsts::fast_k2s): what multiplies r / den in the pressure term
    float rx, ry, rz, vx, vy, vz;
    float pgx, pgy, pgz, vtx, vty, vtz;
 };
@@ -104,7 +104,7 @@ __device__ __forceinline__ void accel_begin(const PairConsts& k, AccelState& s, 
    const float rhoi_inv2 = s.rhoi_inv * s.rhoi_inv;
    s.pi_div_rhoi2 = pi * rhoi_inv2;
    s.visc_scale = k.viscosity * s.rhoi_inv;
-   s.k2s = (k.kernel2 * k.sim_scale) * 0x1p-64f;
+   s.k2s = k.fast_k2s;
    s.rx = posm.x; s.ry = posm.y; s.rz = posm.z;
    s.vx = velp.x; s.vy = velp.y; s.vz = velp.z;
    s.pgx = s.pgy = s.pgz = 0.0f;
@@ -186,7 +186,9 @@ __device__ __forceinline__ void accel_pair_fast_pressure(const PairConsts& k, Ac
    // reference does and met 0 * inf where the reference's clamp of an overflowed |a|^2 returns zeros
    // (seeded random scene 1751 of the soak).  Now: c = (h - d)^2 * (A * (m B)) as the reference
    // forms it - it overflows when the reference's does - and the scalar k2 / den it is multiplied
-   // with carries a factor 2^-64 that accel_fast_finish() takes out of the finished sum: the
+   // with carries a power of two (2^-shift, taken from the exponent of k2 * sim_scale so that the
+   // scaled constant is a normal number of magnitude ~2^-7 for any h and sim_scale: PairConsts::fast_k2s)
+   // that accel_fast_finish() takes out of the finished sum: the
    // per-pair factor f cannot overflow unless c has, whatever the pair's r is, and a sum the
    // reference overflows overflows here when the factor is taken out (5 multiplications and 3 fused
    // multiply-adds per neighbour; the reference's own grouping, g = k2 r / den per component, costs 7 + 3
@@ -198,12 +200,12 @@ __device__ __forceinline__ void accel_pair_fast_pressure(const PairConsts& k, Ac
    s.pgz = __builtin_fmaf(dz, f, s.pgz);
 }
 
-// the pressure sum of a FAST context is accumulated times 2^-64 (accel_pair_fast_pressure): before accel_end
-__device__ __forceinline__ void accel_fast_finish(AccelState& s)
+// the pressure sum of a FAST context is accumulated times 2^-shift (accel_pair_fast_pressure): before accel_end
+__device__ __forceinline__ void accel_fast_finish(const PairConsts& k, AccelState& s)
 {
-   s.pgx *= 0x1p64f;
-   s.pgy *= 0x1p64f;
-   s.pgz *= 0x1p64f;
+   s.pgx *= k.fast_unscale;
+   s.pgy *= k.fast_unscale;
+   s.pgz *= k.fast_unscale;
 }
 
 // viscosity, rescaled inside the neighbour loop (:880-882)

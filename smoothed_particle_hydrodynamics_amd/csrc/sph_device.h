@@ -119,6 +119,10 @@ struct TileCaps {
 struct PairConsts {
    float h2, hscaled, hscaled2, sim_scale;
    float h2_screen;   // h2 widened for the density pass's fused-multiply-add screening test
+   // FAST pressure sum: kernel2 * sim_scale times a power of two 2^-s chosen from ITS exponent so that
+   // the product is a normal number of magnitude [2^-8, 2^-7) whatever h and sim_scale are (a fixed
+   // 2^-64 went subnormal for h_scaled ~ 1e3 and up), and 2^s, which takes it out of the finished sum
+   float fast_k2s, fast_unscale;
    float kernel1, kernel2, kernel3;
    float rho0, stiffness, viscosity;
    float grav_const, central_mass, cx, cy, cz, softening;

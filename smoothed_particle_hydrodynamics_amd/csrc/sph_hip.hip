@@ -51,6 +51,20 @@ PairConsts pair_consts(const sph_hip_params& p)
    k.kernel1 = p.kernel1;
    k.kernel2 = p.kernel2;
    k.kernel3 = p.kernel3;
+   {
+      // (pair_math.h: accel_pair_fast_pressure) |k2 s| * 2^-shift in [2^-8, 2^-7): times 1 / (d + 0.01)
+      // <= 100 the per-pair factor stays below 1, so it cannot overflow unless the reference's own
+      // term has; a zero or non-finite product keeps shift 0
+      const float k2s = p.kernel2 * p.sim_scale;
+      int e = 0, shift = 0;
+      if (std::isfinite(k2s) && k2s != 0.0f) {
+         (void)frexpf(k2s, &e);            // |k2s| = m * 2^e, m in [0.5, 1)
+         shift = e + 7;
+         shift = shift < -120 ? -120 : shift > 120 ? 120 : shift;
+      }
+      k.fast_k2s = ldexpf(k2s, -shift);
+      k.fast_unscale = ldexpf(1.0f, shift);
+   }
    k.rho0 = p.rho0;
    k.stiffness = p.stiffness;
    k.viscosity = p.viscosity;
@@ -954,7 +968,9 @@ static int create_impl(sph_hip_context** out, const sph_hip_params* params, int 
    }
    // FULL with the tolerance-mode pair arithmetic (SPH_HIP_ARITH=fast: experiments run the tools
    // that create plain FULL contexts - A/B, ablation, slab cost - in that mode)
-   const char* arith_env = getenv("SPH_HIP_ARITH");
+   // - only together with SPH_HIP_ALLOW_DIAGNOSTIC=1, which those tools set: a variable left over
+   // in a shell must not turn the bit-exact gates and bench.py's exact record into FAST runs)
+   const char* arith_env = getenv_flag("SPH_HIP_ALLOW_DIAGNOSTIC") ? getenv("SPH_HIP_ARITH") : nullptr;
    const bool fast = mode == SPH_HIP_MODE_FULL_FAST ||
                      (mode == SPH_HIP_MODE_FULL && arith_env && strcmp(arith_env, "fast") == 0);
    if (fast) mode = SPH_HIP_MODE_FULL;

@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# a variable left over from tools/ (diagnostic runs) must not change what the gates test
+os.environ.pop("SPH_HIP_ARITH", None)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

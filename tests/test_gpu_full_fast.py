@@ -8,13 +8,17 @@ viscous rescale inside the loop (:880-882) - and relaxes the per-pair arithmetic
 
 Bar (against the CPU oracle, every step started from the SAME state on both sides):
   * neighbour counts identical;
-  * acceleration: |a - a_ref| <= 1e-4 * max(|a|, |a_ref|) per particle (the north star's tolerance),
-    read against what the acceleration is a sum OF: a particle's ~30 pair terms of either sign
-    (src/sph.cpp:866-882) largely cancel in a fluid near rest, and where they cancel to less than
-    a hundredth of their magnitude sum T (oracle_full_accel_scale), any evaluation that is not the
-    reference's bit for bit - the reference's own -ffast-math build included - differs from it by
-    rounding errors of the terms.  Such a particle passes with |a - a_ref| <= 1e-6 * T (16 fp32
-    ulps of the magnitude sum); at most 0.5 % of a scene's particles may need that clause;
+  * acceleration: |a - a_ref| <= 1e-4 * max(|a|, |a_ref|) for EVERY particle - the north star's
+    tolerance, asserted as written (STRICT) in every test of this file, of test_gpu_full_size.py
+    and of test_gpu_c4_c5.py, i.e. on every BASELINE configuration and on every committed scene.
+    One escape clause exists and is used by tests/test_gpu_random_scenes.py ONLY (adversarial
+    seeded draws: clusters, duplicates, densities next to rho0), which prints how many particles
+    took it: a particle's ~30 pair terms of either sign (src/sph.cpp:866-882) can cancel to less
+    than a hundredth of their magnitude sum T (oracle_full_accel_scale), and there any evaluation
+    that is not the reference's bit for bit - the reference's own -ffast-math build included -
+    differs from it by rounding errors of the terms; such a particle passes with
+    |a - a_ref| <= 1e-6 * T (16 fp32 ulps of the magnitude sum), at most 0.5 % of a scene's
+    particles may need it (check_fast(..., scale=...): the clause is on only when a scale is given);
   * density: IDENTICAL to the oracle - the density sum keeps the reference's arithmetic (the pressure
     p = (rho - rho0) * k amplifies an error of rho by rho / (rho - rho0): a tolerance-mode density
     sum 2e-6 off made accelerations 4e-4 off next to particles whose density is near rho0);
@@ -25,6 +29,8 @@ Bar (against the CPU oracle, every step started from the SAME state on both side
     new position within 1e-6 of the cell edge (+ 2 ulps of the coordinate).
 The exact mode (tests/test_gpu_full_mode.py) stays the bit-for-bit gate.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -35,10 +41,12 @@ pytestmark = pytest.mark.gpu
 FORCE_RTOL = 1e-4
 FORCE_COND_TOL = 1e-6      # of the magnitude sum of a particle's terms
 FORCE_COND_SHARE = 0.005   # particles that may need the second clause
+CLAUSE_USED = {"particles": 0, "scenes": 0}   # how often the clause was taken (random scenes only)
 
 
 def check_fast(part, ref, p, mass, what="", scale=None):
-    """-> (largest relative force error, the absolute force error each particle was allowed)"""
+    """-> (largest relative force error, the absolute force error each particle was allowed).
+    scale=None (every caller but the random scenes): STRICT - 1e-4 relative for every particle."""
     assert np.array_equal(part.mNeighborCount, ref["ncount"]), "%s neighbour counts differ at %d particles" % (
         what, int((part.mNeighborCount != ref["ncount"]).sum()))
     assert np.array_equal(part.mDensity, ref["rho"]), what + " density not bit-identical"
@@ -56,6 +64,10 @@ def check_fast(part, ref, p, mass, what="", scale=None):
             what, cond.max(), rel.max())
         assert over.mean() <= FORCE_COND_SHARE, "%s: %d particles beyond 1e-4 relative" % (what, int(over.sum()))
         allowed = np.maximum(allowed, FORCE_COND_TOL * T)
+        CLAUSE_USED["particles"] += int(over.sum())
+        CLAUSE_USED["scenes"] += 1
+        print("%s: %d of %d particles beyond 1e-4 relative took the cancellation clause (worst %.3g of the "
+              "terms' magnitude sum)" % (what, int(over.sum()), rel.size, float(cond.max())))
     return rel.max(), allowed
 
 
@@ -86,8 +98,7 @@ def run_fast(oracle, p, pos, vel, mass, steps=1, mode=None):
             part = sph.getParticles()
             opos, ovel = cur_pos.copy(), cur_vel.copy()
             ref = oracle.step(op, opos, ovel, mass, mode="full")
-            w, allowed = check_fast(part, ref, p, mass, "step %d" % s,
-                                    scale=lambda: oracle.full_accel_scale(op, cur_pos, cur_vel, mass, ref["rho"]))
+            w, allowed = check_fast(part, ref, p, mass, "step %d" % s)      # strict: no clause
             worst = max(worst, w)
             check_fast_velocity(part.mVelocity, ovel, allowed, p.time_step, "step %d" % s)
             assert (np.abs(part.mPosition.astype(np.float64) - opos) <=
@@ -108,7 +119,17 @@ def test_fast_dam_break_256k_moving(oracle, hiplib):
     """BASELINE config C2, with a velocity field so that the viscous sum is live"""
     from smoothed_particle_hydrodynamics_amd import scenes
     p, pos, vel, mass = scenes.dam_break(262144, speed=0.05)
-    run_fast(oracle, p, pos, vel, mass, steps=2)
+    worst = run_fast(oracle, p, pos, vel, mass, steps=2)
+    print("C2 moving, tolerance mode: worst force rel err %.3g (bar 1e-4, every particle)" % worst)
+
+
+def test_fast_dam_break_256k_at_rest(oracle, hiplib):
+    """BASELINE config C2 as the dam-break starts (the state bench.py steps): all 262 144 particles
+    against the oracle, three steps"""
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dam_break(262144)
+    worst = run_fast(oracle, p, pos, vel, mass, steps=3)
+    print("C2 at rest, tolerance mode: worst force rel err %.3g (bar 1e-4, every particle)" % worst)
 
 
 def test_fast_dense_block_with_point_mass_and_motion(oracle, hiplib):
@@ -146,6 +167,61 @@ def test_fast_distances_below_the_fast_root_s_range(oracle, hiplib):
     from test_gpu_full_mode import _tiny_distance_scene
     p, pos, vel, mass = _tiny_distance_scene()
     run_fast(oracle, p, pos, vel, mass, steps=2)
+
+
+def test_fast_large_smoothing_length(oracle, hiplib):
+    """h = 1e4 (the reference's comments speak of astrophysical units): kernel2 = -45 / (pi h^6) =
+    -1.4e-23.  The pressure sum's running scale is taken from the exponent of kernel2 * sim_scale
+    (PairConsts::fast_k2s); the fixed 2^-64 of round 3 left 9 significant bits of it here."""
+    from smoothed_particle_hydrodynamics_amd import default_params, scenes
+    h = 1.0e4
+    p = default_params(h, (4, 4, 4))
+    p.central_mass = 0.0
+    assert abs(p.kernel2 * p.sim_scale) < 2e-19
+    n = 1500
+    pos = scenes.box_fill(n, (2.0e4,) * 3, (6.8e4,) * 3, seed=3)
+    vel = scenes.box_fill(n, (-50.0,) * 3, (50.0,) * 3, seed=4)
+    for mscale in (1.0, 1.0e11):          # negative pressures (rhoiInv = 1) / positive ones
+        mass = (np.float32(mscale) * (0.5 + scenes.uniform01(11, np.arange(n)))).astype(np.float32)
+        # (positive pressures of ~5e-4 make the in-loop viscous rescale mu / p_i = 20 per neighbour
+        # with the default mu: the reference's own sum overflows after 30 of them)
+        p.viscosity = 0.01 if mscale == 1.0 else 1.0e-5
+        run_fast(oracle, p, pos, vel, mass, steps=2)
+
+
+def test_fast_subnormal_pressure_of_a_lane_past_its_count(oracle, hiplib):
+    """rho0 = -1e-36: an isolated particle (rho = 0) has the pressure 1e-39, a positive subnormal,
+    1 / p = inf and A = p * rhoiInv^2 = inf.  In the tiled pressure loop a lane past its count takes
+    itself as a neighbour of factor zero: 0 * inf must not reach its sum (every route the same bits,
+    and the oracle's: the particle's acceleration is the point-mass term alone)."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import scenes
+    p, pos, vel, mass = scenes.dense_block(4000, lo=(1.0, 1.0, 1.0), hi=(1.8, 1.8, 1.8))
+    p.rho0 = -1.0e-36
+    pos = pos.reshape(-1, 3)
+    # isolated particles: in the sorted order they share waves with the block's busy lanes only if
+    # their cells are adjacent in cell-id order - put them right beside the block, one cell row away
+    pos[5] = [1.4, 1.4, 2.05]
+    pos[6] = [1.0, 2.05, 1.4]
+    pos[7] = [0.6, 1.4, 1.4]
+    pos = np.ascontiguousarray(pos.reshape(-1))
+    run_fast(oracle, p, pos, vel, mass, steps=2)
+    out = []
+    for env in ({}, {"SPH_HIP_UNTILED": "1"}):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            with S.SPH(mass.size, p, mode=S.MODE_FULL_FAST) as sph:
+                sph.setParticles(pos, vel, mass)
+                sph.step()
+                part = sph.getParticles()
+                out.append((part.mAcceleration.copy(), part.mNeighborCount.copy()))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert (out[0][1][5:8] == 0).all()
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0])
 
 
 @pytest.mark.parametrize("n", [1, 2, 64, 257])

@@ -79,7 +79,8 @@ SOAK_FINDS = [c for c in (219, 305, 1751) if c >= CASES]
 @pytest.mark.parametrize("case", list(range(CASES)) + SOAK_FINDS)
 def test_random_scene_tolerance_mode(oracle, hiplib, case):
     """the same draws with SPH_HIP_MODE_FULL_FAST, held to tests/test_gpu_full_fast.py's bar (every
-    step started from the state the GPU started from)"""
+    step started from the state the GPU started from) - the ONLY tests in which the cancellation
+    clause of that bar may be taken (check_fast prints every particle that takes it)"""
     import smoothed_particle_hydrodynamics_amd as S
     from test_gpu_full_fast import check_fast, check_fast_velocity
     p, pos, vel, mass = draw(case)

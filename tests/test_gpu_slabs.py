@@ -408,3 +408,43 @@ def test_rebalancing_and_trimmed_messages_on_the_gpu(hiplib, tmp_path):
         assert int(d["device_rebalances"]) == int(d["rebalances"])
         assert int(d["active"]) < 20000
     assert seen.all()
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-slab-step", "separate-kernels"])
+def test_slab_energies_add_up_when_workgroups_give_up(hiplib, monkeypatch, fused):
+    """A two-part acceleration launch walks the give-up list in BOTH parts; only the part that owns
+    a listed workgroup may write its energy partial sums (the other part's zeros raced with them on
+    the unordered streams: round-3 advice).  8 logical slabs with tile capacities forced so small
+    that most workgroups are on the give-up lists - some with lists (they fit one pass only), some
+    without - early exchange on two streams: the slabs' KE / PE add up to the single context's."""
+    import smoothed_particle_hydrodynamics_amd as S
+    from helpers import energy_rtol
+    from smoothed_particle_hydrodynamics_amd import scenes
+    monkeypatch.setenv("SPH_HIP_TILE_CAP", "1024")
+    monkeypatch.setenv("SPH_HIP_TILE_CAP_ACCEL", "768")
+    monkeypatch.setenv("SPH_HIP_TILE_CAP_DENSITY", "896")
+    if fused:
+        monkeypatch.delenv("SPH_HIP_NO_FUSED_SLAB", raising=False)
+    else:
+        monkeypatch.setenv("SPH_HIP_NO_FUSED_SLAB", "1")
+    p, pos, vel, mass = scenes.dam_break(160000, speed=0.05)
+    p.central_mass = 1.0e5       # a potential energy to add up as well
+    group, cuts = build_group(S, p, pos, vel, mass, 8, "two-streams")
+    for _ in range(3):
+        group.step()
+    gave_up = sum(s.tile_stats()["untiled_acceleration"] for s in group.slabs)
+    assert gave_up > 50, gave_up
+    ke = sum(np.float64(s.energy()[0]) for s in group.slabs)
+    pe = sum(np.float64(s.energy()[1]) for s in group.slabs)
+    got = group.gather(mass.size)
+    for s in group.slabs:
+        assert s.status()["errors"] == 0
+        s.close()
+    with S.SPH(mass.size, p) as one:
+        one.setParticles(pos, vel, mass)
+        one.run(3)
+        want = one.energy()
+        part = one.getParticles()
+        assert np.array_equal(got["pos"], part.mPosition) and np.array_equal(got["vel"], part.mVelocity)
+    assert ke == pytest.approx(want[0], rel=energy_rtol(mass.size))
+    assert pe == pytest.approx(want[1], rel=energy_rtol(mass.size))
