@@ -62,18 +62,25 @@ __device__ __forceinline__ void integrate_particle(const PairConsts& k, float4& 
    const float ny0 = x.y + (vhy * pos_dt);
    const float nz0 = x.z + (vhz * pos_dt);
 
-   float rsx = (nx0 - k.cx), rsy = (ny0 - k.cy), rsz = (nz0 - k.cz);
-   if (!UNIT_SCALE) {
-      rsx *= k.sim_scale;
-      rsy *= k.sim_scale;
-      rsz *= k.sim_scale;
+   // (k.skip_point_mass: tolerance mode without a point mass - the term is +-0, see accel_end; d3 then
+   // only divides a potential energy of exactly zero)
+   float agx = 0.0f, agy = 0.0f, agz = 0.0f, d3 = 1.0f;
+   if (!k.skip_point_mass) {
+      float rsx = (nx0 - k.cx), rsy = (ny0 - k.cy), rsz = (nz0 - k.cz);
+      if (!UNIT_SCALE) {
+         rsx *= k.sim_scale;
+         rsy *= k.sim_scale;
+         rsz *= k.sim_scale;
+      }
+      float dot = rsx * rsx + rsy * rsy + rsz * rsz;
+      dot = sqrtf(dot);
+      const float ds = dot + k.softening;
+      d3 = ds * ds * ds;
+      const float gm = -k.grav_const * k.central_mass;
+      agx = gm * (rsx / d3);
+      agy = gm * (rsy / d3);
+      agz = gm * (rsz / d3);
    }
-   float dot = rsx * rsx + rsy * rsy + rsz * rsz;
-   dot = sqrtf(dot);
-   const float ds = dot + k.softening;
-   const float d3 = ds * ds * ds;
-   const float gm = -k.grav_const * k.central_mass;
-   float agx = gm * (rsx / d3), agy = gm * (rsy / d3), agz = gm * (rsz / d3);
    if (k.apply_gravity) { // extension, as in accel_end
       agx += k.gx;
       agy += k.gy;
@@ -91,7 +98,7 @@ __device__ __forceinline__ void integrate_particle(const PairConsts& k, float4& 
       nx = np[0]; ny = np[1]; nz = np[2];
    }
 
-   dot = nvx * nvx + nvy * nvy + nvz * nvz;
+   const float dot = nvx * nvx + nvy * nvy + nvz * nvz;
    ke = 0.0;
    pe = 0.0;
    if (dot > 0) {

@@ -35,6 +35,42 @@
 #error "SPH_ABLATE is for diagnostic builds only: add -DSPH_DIAGNOSTIC_BUILD (tools/build_variant.sh does)"
 #endif
 
+// SPH_TRIPCOUNT (diagnostic builds only, tools/trip_counts.py): counts how often the loops of the two
+// pair kernels run - per wave ("W": once per wave whenever ANY lane takes the trip: what the SIMD
+// issues) and per lane ("L": what the particles need) - into g_trip[], read by sph_hip_diag_trips().
+// Results stay correct; the timing of such a build means nothing.
+#ifdef SPH_TRIPCOUNT
+#ifndef SPH_DIAGNOSTIC_BUILD
+#error "SPH_TRIPCOUNT is for diagnostic builds only: add -DSPH_DIAGNOSTIC_BUILD"
+#endif
+enum {
+   TRIP_D_WAVES = 0, TRIP_D_CHUNKS_W, TRIP_D_TEST8_W, TRIP_D_TEST8_L, TRIP_D_SLOTS_L, TRIP_D_POPS_W,
+   TRIP_D_POPS_L, TRIP_D_POPLOOPS_W, TRIP_D_SUMTRIPS_W, TRIP_D_SUMSLOTS_W, TRIP_D_LISTED_L, TRIP_D_LANES_L,
+   TRIP_A_WAVES = 16, TRIP_A_PTRIPS_W, TRIP_A_CNT_L, TRIP_A_VTRIPS_W, TRIP_A_NV_L, TRIP_A_LANES_L,
+   TRIP_COUNT = 32
+};
+__device__ unsigned long long g_trip[TRIP_COUNT];
+struct TripCounters {
+   unsigned int v[16];
+   __device__ TripCounters() { for (int i = 0; i < 16; i++) v[i] = 0; }
+   // per-wave counter: every lane adds the same value; flush takes lane 0's
+   __device__ void wave(int i, bool any_lane) { v[i] += any_lane ? 1u : 0u; }
+   __device__ void lane(int i, unsigned int n) { v[i] += n; }
+   __device__ void flush(int base, unsigned int lane_mask /* bit i: v[i] is a per-lane sum */)
+   {
+      for (int i = 0; i < 16; i++) {
+         unsigned int x = v[i];
+         if (lane_mask >> i & 1u)
+            for (int o = SPH_WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+         if ((threadIdx.x & (SPH_WAVE - 1)) == 0 && x) atomicAdd(&g_trip[base + i], (unsigned long long)x);
+      }
+   }
+};
+#define TRIP(x) x
+#else
+#define TRIP(x)
+#endif
+
 // The tile lives in dynamic LDS: its capacity (candidate positions per workgroup) is a launch
 // parameter, chosen by the host from the tile sizes the previous steps needed, because the
 // workgroups a CU can hold (and with them the latency hiding of both passes) is set by the LDS
@@ -468,6 +504,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    uint32_t* list_block = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS);
 
    const float h2_screen = k.h2_screen;
+   TRIP(TripCounters trips; trips.wave(TRIP_D_WAVES, true); trips.lane(TRIP_D_LANES_L, live ? 1u : 0u);)
    int count = 0;
    // The list is a column of 16-bit entries: entry j of this lane is the (j & 1) half of word
    // (j >> 1) * TILE_THREADS + tid.  TEST stores every accepted neighbour with one 2-byte store
@@ -483,8 +520,14 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       const int ts = (int)r.s[kk] + D;
       const int te = (int)r.e[kk] + D;
       // chunks of 32 tile slots starting at a 4-aligned slot; one acceptance bit per slot
+      TRIP(trips.lane(TRIP_D_SLOTS_L, te > ts ? (unsigned)(te - ts) : 0u);)
       for (int t0 = (ts < te) ? (ts & ~3) : te; __any(t0 < te); t0 += 32) {
          uint32_t mask = 0;
+         TRIP(trips.wave(TRIP_D_CHUNKS_W, true);
+              for (int q8 = 0; q8 < 4; q8++) {
+                 trips.wave(TRIP_D_TEST8_W, __any(t0 + 8 * q8 < te));
+                 trips.lane(TRIP_D_TEST8_L, t0 + 8 * q8 < te ? 1u : 0u);
+              })
 #if defined(SPH_ABLATE) && SPH_ABLATE == 2
          if (false) {
 #else
@@ -516,8 +559,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
          // append the set bits, ascending, to the lane's neighbour list
          const uint32_t ebase = kbits | (uint32_t)t0;
          while (__any(mask != 0u)) {
+            TRIP(trips.wave(TRIP_D_POPLOOPS_W, true);)
 #pragma unroll
             for (int rep = 0; rep < APPEND_POPS; rep++) {   // several pops per trip: less loop control
+               TRIP(trips.wave(TRIP_D_POPS_W, __any(mask != 0u)); trips.lane(TRIP_D_POPS_L, mask != 0u ? 1u : 0u);)
                if (mask != 0u) {
                   const uint32_t bit = (uint32_t)__builtin_ctz(mask);
                   mask &= mask - 1u;
@@ -595,7 +640,10 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const uint32_t* sum_list = list_block + tid;
    const int listed = overflowed ? 0 : count;   // entries to sum from the list
    int kept = 0;
+   TRIP(trips.lane(TRIP_D_LISTED_L, (unsigned)listed);)
    for (int j0 = 0; __any(j0 < listed); j0 += DENSITY_UNROLL) {
+      TRIP(trips.wave(TRIP_D_SUMTRIPS_W, true);
+           for (int u = 0; u < DENSITY_UNROLL; u++) trips.wave(TRIP_D_SUMSLOTS_W, __any(j0 + u < listed));)
 #if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
       uint32_t entry[DENSITY_UNROLL];
       const int lastw = listed > 0 ? (listed - 1) >> 1 : 0;
@@ -633,6 +681,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       if (kept & 1) my_entries[(kept >> 1) * (2 * TILE_THREADS) + 1] = (uint16_t)0;
       count = kept;
    }
+   TRIP(trips.flush(0, 1u << TRIP_D_TEST8_L | 1u << TRIP_D_SLOTS_L | 1u << TRIP_D_POPS_L | 1u << TRIP_D_LISTED_L |
+                       1u << TRIP_D_LANES_L);)
    if (live) {
       rho_out[p] = density;
       const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
@@ -1262,7 +1312,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       // positive subnormal (1 / p_i = inf), and 0 * inf would poison a sum the list-walking routes leave
       // untouched: a wave holding such a lane - never seen outside a test - selects the factor instead.)
       const bool odd_lane = __any(!__builtin_isfinite(s.pi_div_rhoi2));
+      TRIP(TripCounters trips; trips.wave(TRIP_A_WAVES - 16, true); trips.lane(TRIP_A_CNT_L - 16, (unsigned)cnt);
+           trips.lane(TRIP_A_LANES_L - 16, live ? 1u : 0u); trips.lane(TRIP_A_NV_L - 16, (unsigned)(cnt - first_v));)
       for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
+         TRIP(trips.wave(TRIP_A_PTRIPS_W - 16, true);)
 #pragma unroll
          for (int u = 0; u < ACCEL_UNROLL; u++)
             entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
@@ -1305,6 +1358,8 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       // The viscous sum over the list's last visc_keep() entries (ascending, as everywhere): the
       // only neighbours whose {v, C} is gathered, with the reference's stored distance.
       const int nv = cnt - first_v;
+      TRIP(for (int m0 = 0; __any(m0 < nv); m0 += VISC_UNROLL) trips.wave(TRIP_A_VTRIPS_W - 16, true);
+           trips.flush(16, 1u << (TRIP_A_CNT_L - 16) | 1u << (TRIP_A_NV_L - 16) | 1u << (TRIP_A_LANES_L - 16));)
       for (int m0 = 0; __any(m0 < nv); m0 += VISC_UNROLL) {
          float4 vj[VISC_UNROLL];
          int tj[VISC_UNROLL];

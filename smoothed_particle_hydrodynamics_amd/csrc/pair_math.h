@@ -237,7 +237,10 @@ __device__ __forceinline__ int visc_keep(float visc_scale)
    return m < 1.0f ? 1 : (int)m;
 }
 
-// reference src/sph.cpp:888-933
+// reference src/sph.cpp:888-933.  k.skip_point_mass (tolerance mode only, set by the host): a scene
+// without a point mass (the dam-break: central_mass = 0, so every term of the block is +-0) skips
+// the term's square root and three divisions behind a uniform branch; the exact mode evaluates it
+// always (x + -0 keeps a -0 that x + +0 does not).
 template <bool UNIT_SCALE>
 __device__ __forceinline__ float4 accel_end(const PairConsts& k, const AccelState& s)
 {
@@ -245,6 +248,7 @@ __device__ __forceinline__ float4 accel_end(const PairConsts& k, const AccelStat
    float ay = s.vty - s.pgy;
    float az = s.vtz - s.pgz;
 
+   if (!k.skip_point_mass) {
    float rsx = (s.rx - k.cx), rsy = (s.ry - k.cy), rsz = (s.rz - k.cz);
    if (!UNIT_SCALE) {
       rsx *= k.sim_scale;
@@ -259,13 +263,14 @@ __device__ __forceinline__ float4 accel_end(const PairConsts& k, const AccelStat
    ax += gm * (rsx / d3);
    ay += gm * (rsy / d3);
    az += gm * (rsz / d3);
+   }
    if (k.apply_gravity) { // extension: uniform gravity enters next to the point-mass term
       ax += k.gx;
       ay += k.gy;
       az += k.gz;
    }
 
-   dot = (ax * ax) + (ay * ay) + (az * az);
+   const float dot = (ax * ax) + (ay * ay) + (az * az);
    if (dot > k.cfl_limit2) {
       const float length = sqrtf(dot);
       const float scale = k.cfl_limit / length;

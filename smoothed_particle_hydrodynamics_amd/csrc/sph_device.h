@@ -133,6 +133,9 @@ struct PairConsts {
    float damping;            // mDamping
    float max_x, max_y, max_z; // mMaxX/Y/Z
    int apply_gravity, apply_walls;
+   // tolerance mode, no point mass (central_mass == 0, softening > 0): the point-mass terms of
+   // computeAcceleration / integrate (src/sph.cpp:892-915, 966-989) are +-0 and are skipped
+   int skip_point_mass;
 };
 
 struct sph_hip_context {

@@ -36,7 +36,7 @@ void bind_flags(F&& f, bool flag, Rest... rest)
    else bind_flags([&](auto... later) { f(std::false_type{}, later...); }, rest...);
 }
 
-PairConsts pair_consts(const sph_hip_params& p)
+PairConsts pair_consts(const sph_hip_params& p, bool fast)
 {
    PairConsts k;
    k.h2 = p.h2;
@@ -87,6 +87,7 @@ PairConsts pair_consts(const sph_hip_params& p)
    k.max_z = p.max_z;
    k.apply_gravity = p.apply_gravity;
    k.apply_walls = p.apply_walls;
+   k.skip_point_mass = fast && p.central_mass == 0.0f && p.softening > 0.0f && std::isfinite(p.grav_const) ? 1 : 0;
    return k;
 }
 
@@ -652,7 +653,7 @@ int launch_density(sph_hip_context* ctx)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
-   const PairConsts k = pair_consts(ctx->prm);
+   const PairConsts k = pair_consts(ctx->prm, ctx->fast != 0);
    const int blocks = div_up(n, 256);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_ref_density, dim3(blocks), dim3(256), 0, ctx->stream, ctx->posm[0],
@@ -680,7 +681,7 @@ int launch_accel(sph_hip_context* ctx, int part = 0, hipStream_t part_stream = n
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
-   const PairConsts k = pair_consts(ctx->prm);
+   const PairConsts k = pair_consts(ctx->prm, ctx->fast != 0);
    const int blocks = div_up(n, 256);
    if (ctx->mode == SPH_HIP_MODE_REF) {
       hipLaunchKernelGGL(k_ref_accel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->posm[0],
@@ -708,7 +709,7 @@ int launch_integrate(sph_hip_context* ctx, bool with_hash = false)
 {
    const int n = ctx->n;
    if (n == 0) return SPH_HIP_OK;
-   const PairConsts k = pair_consts(ctx->prm);
+   const PairConsts k = pair_consts(ctx->prm, ctx->fast != 0);
    const int blocks = div_up(n, RED_THREADS);
 #define SPH_GO(U, H)                                                                             \
    hipLaunchKernelGGL((k_integrate<U, H>), dim3(blocks), dim3(RED_THREADS), 0, ctx->stream,       \
@@ -882,6 +883,23 @@ extern "C" {
 int sph_hip_abi_version(void) { return SPH_HIP_ABI_VERSION | SPH_HIP_ABI_DIAGNOSTIC; }
 #else
 int sph_hip_abi_version(void) { return SPH_HIP_ABI_VERSION; }
+#endif
+
+#ifdef SPH_TRIPCOUNT
+// diagnostic builds with -DSPH_TRIPCOUNT only (tools/trip_counts.py): the loop trip counters of the
+// pair kernels (csrc/full_tiled.h: TRIP_*), accumulated since the last reset
+extern "C" int sph_hip_diag_trips(unsigned long long* out, int n, int reset)
+{
+   unsigned long long h[TRIP_COUNT];
+   if (hipDeviceSynchronize() != hipSuccess ||
+       hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trip), sizeof(h)) != hipSuccess) return SPH_HIP_ERR_DEVICE;
+   for (int i = 0; i < n && i < TRIP_COUNT; i++) out[i] = h[i];
+   if (reset) {
+      memset(h, 0, sizeof(h));
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_trip), h, sizeof(h)) != hipSuccess) return SPH_HIP_ERR_DEVICE;
+   }
+   return SPH_HIP_OK;
+}
 #endif
 
 int sph_hip_selftest_sqrt(int device, uint64_t* mismatches, uint32_t* first_bad)
@@ -1646,7 +1664,7 @@ int sph_hip_slab_step_begin(sph_hip_context* ctx, void* left_device, void* right
       return SPH_HIP_OK;
    }
    if ((rc = launch_accel(ctx, 1, side))) return rc;
-   const PairConsts k = pair_consts(ctx->prm);
+   const PairConsts k = pair_consts(ctx->prm, ctx->fast != 0);
    const SlabZone zone = slab_zone(ctx);
    if (unit_scale(ctx->prm))
       hipLaunchKernelGGL(k_slab_pack_early<true>, dim3(SLAB_PACK_BLOCKS), dim3(256), 0, side,

@@ -20,7 +20,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     out = []
     for n in sizes:
         p, pos, vel, mass = scenes.dam_break(n)
-        sph = S.SPH(n, p)
+        # AB_MODE=fast: the tolerance-mode arithmetic (bench.py's headline); default: bit-exact
+        sph = S.SPH(n, p, mode=S.MODE_FULL_FAST if os.environ.get("AB_MODE") == "fast" else S.MODE_FULL)
         sph.setParticles(pos, vel, mass)
         sph.run(10)
         sph.synchronize()
@@ -39,7 +40,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
             out.append("[build %.0f density %.0f accel %.0f integrate %.0f us]" % (
                 t[0] / k * 1e3, t[2] / k * 1e3, t[4] / k * 1e3, t[5] / k * 1e3))
         sph.close()
-    print("%-22s" % os.path.basename(os.environ.get("SPH_HIP_LIBRARY", "default")), " | ".join(out), flush=True)
+    print("%-22s %-5s" % (os.path.basename(os.environ.get("SPH_HIP_LIBRARY", "default")),
+                          os.environ.get("AB_MODE", "exact")), " | ".join(out), flush=True)
 else:
     for rnd in range(2):
         for so in sorted(glob.glob(os.path.join(ROOT, "build", "variants", "*.so"))):
