@@ -83,6 +83,7 @@ def parse_args():
                          "print {\"dry_run\": true, \"ranks\": N}; no GPU work (checks a node's "
                          "launch shape, and runs in the CPU test suite)")
     ap.add_argument("--preflight-child", metavar="STORE", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--preflight-kind", choices=("native", "torch"), default="torch", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -102,14 +103,19 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
-PREFLIGHT_TIMEOUT_S = 240
+PREFLIGHT_TIMEOUT_S = 150       # per stage (native, then torch P2P)
 
 
 def preflight_child(args):
     """Helper process of one rank (started by preflight() below, before that rank has touched
-    the GPU): bring RCCL up, exchange one small message with each neighbour, exit 0 if it arrived.
-    Anything else - an exception, a wrong byte, a hang that the parent's timeout ends - means the
-    ranks stage their halo messages through the host instead."""
+    the GPU): bring the device-to-device path of `args.preflight_kind` up, exchange one checked
+    message with each neighbour, exit 0 if it arrived.
+      native  libsph_hip.so's own RCCL calls: a small slab context per rank, sph_hip_slab_comm_init
+              (the communicator id travels through a file store) and sph_hip_slab_comm_exchange_check
+              - ncclSend/ncclRecv of both directions in one group on the exchange stream, exactly what
+              sph_hip_slab_comm_run issues every step;
+      torch   torch.distributed P2P (batch_isend_irecv, backend nccl = RCCL).
+    Anything else - an exception, a wrong byte, a hang that the parent's timeout ends - is a 'no'."""
     import datetime
     import torch
     import torch.distributed as dist
@@ -119,39 +125,77 @@ def preflight_child(args):
     code = 3
     try:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", init_method="file://" + args.preflight_child, rank=rank,
-                                world_size=world, timeout=datetime.timedelta(seconds=90),
-                                device_id=torch.device("cuda", local_rank))
-        if SL.neighbour_exchange_works(rank, world, "cuda", timeout_s=60.0):
+        if args.preflight_kind == "native":
+            import smoothed_particle_hydrodynamics_amd as S
+            store = dist.FileStore(args.preflight_child, world)
+            # 4 cell planes per rank (a slab must be at least two halos thick), a handful of entries
+            p = S.default_params(0.05, (2, 2, 2 * world))
+            assert p.full_cells_z >= 4 * world
+            planes = [r * p.full_cells_z // world for r in range(world + 1)]
+            slab = SL.HipSlab(p, planes[rank], planes[rank + 1], 1024, 256, device=local_rank,
+                              has_left=rank > 0, has_right=rank + 1 < world)
+            if rank == 0:
+                store.set("rccl_id", SL.rccl_unique_id())
+            ident = store.get("rccl_id")            # (waits for rank 0)
+            slab.comm_init(ident, rank, world)
+            slab.comm_exchange_check()
             code = 0
+        else:
+            dist.init_process_group("nccl", init_method="file://" + args.preflight_child, rank=rank,
+                                    world_size=world, timeout=datetime.timedelta(seconds=90),
+                                    device_id=torch.device("cuda", local_rank))
+            if SL.neighbour_exchange_works(rank, world, "cuda", timeout_s=60.0):
+                code = 0
     except Exception as exc:      # noqa: BLE001
-        print("pre-flight helper of rank %d: %r" % (rank, exc), file=sys.stderr, flush=True)
+        print("pre-flight helper (%s) of rank %d: %r" % (args.preflight_kind, rank, exc), file=sys.stderr,
+              flush=True)
     sys.stderr.flush()
     os._exit(code)                # no communicator teardown: it may be the thing that hangs
 
 
-def preflight(rank, world):
-    """Does the device-to-device neighbour exchange work on this node?  Asked of a helper process
-    per rank, with a time limit, BEFORE this process initialises the GPU or RCCL: a hang or a crash
-    in there is then a 'no', not a stuck or dead run."""
+def preflight_stage(kind, rank, world):
+    """Does the device-to-device neighbour exchange of `kind` ("native" / "torch") work on this
+    node?  Asked of a helper process per rank, with a time limit, BEFORE this process initialises the
+    GPU or RCCL: a hang or a crash in there is then a 'no', not a stuck or dead run."""
     if os.environ.get("SPH_BENCH_FORCE_P2P_FALLBACK") == "1":
         return False
-    # rendezvous file of the helpers: one per launch (all ranks of a launch are children of the same
-    # torch.distributed.run agent; a file left by an earlier launch must not be found again)
-    store = "/tmp/sph_bench_preflight_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-    cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", store, "--gpus", str(world)]
+    # rendezvous file of the helpers: one per launch and stage (all ranks of a launch are children of
+    # the same torch.distributed.run agent; a file left by an earlier launch must not be found again)
+    store = "/tmp/sph_bench_preflight_%s_%s_%d" % (kind, os.environ.get("MASTER_PORT", "0"), os.getppid())
+    cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", store, "--preflight-kind", kind,
+           "--gpus", str(world)]
     try:
         ok = subprocess.run(cmd, timeout=PREFLIGHT_TIMEOUT_S).returncode == 0
     except subprocess.TimeoutExpired:       # (subprocess.run has killed the child)
-        print("pre-flight helper of rank %d: no answer after %d s" % (rank, PREFLIGHT_TIMEOUT_S),
+        print("pre-flight helper (%s) of rank %d: no answer after %d s" % (kind, rank, PREFLIGHT_TIMEOUT_S),
               file=sys.stderr, flush=True)
         ok = False
-    if rank == 0:
-        try:
-            os.remove(store)
-        except OSError:
-            pass
     return ok
+
+
+def choose_transport(rank, world, torch, dist):
+    """Order of preference: the library's own RCCL loop (no Python in a step) -> torch.distributed
+    P2P -> messages staged through the host over gloo.  Each candidate is tried by every rank's
+    helper process at the same time (the ranks meet over the gloo group between the stages, which
+    needs no GPU), and a 'no' from any rank moves all of them on.  SPH_SLAB_TRANSPORT names one
+    outright (native / torch / host).  -> (mode, what the stages said)"""
+    forced = os.environ.get("SPH_SLAB_TRANSPORT")
+    if forced:
+        return forced, {"forced": forced}
+    said = {}
+    for kind in ("native", "torch"):
+        verdict = torch.tensor([1 if preflight_stage(kind, rank, world) else 0], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        said[kind] = bool(int(verdict.item()))
+        for leftover in ("/tmp/sph_bench_preflight_%s_%s_%d" % (kind, os.environ.get("MASTER_PORT", "0"), os.getppid()),):
+            if rank == 0:
+                try:
+                    os.remove(leftover)
+                except OSError:
+                    pass
+        if said[kind]:
+            return kind, said
+    return "host-fallback", said
 
 
 def cpu_baseline(n_sample, steps, n_total):
@@ -565,18 +609,15 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
         # the upload left the device idle: PREHEAT_STEPS untimed steps of this very run, before the
         # W warm-up steps, let its clocks settle (run_single has the story; the column at rest
         # does not change measurably in that many steps)
-        for _ in range(PREHEAT_STEPS):
-            stepper.step()
-    for _ in range(warmup):
-        stepper.step()
+        stepper.run(PREHEAT_STEPS)
+    stepper.run(warmup)
     fence()
     # from here on only the used part of the halo messages crosses the links (+25 % head room)
     msg_records = stepper.trim_messages() if warmup > 0 else stepper.slab.msg_capacity
     fence()
     stepper.slab.set_timing_stride(PAIR_SAMPLE_EVERY)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        stepper.step()
+    stepper.run(steps)         # (native: the whole loop inside libsph_hip.so; torch: a Python loop over step())
     fence()
     dt_local = time.perf_counter() - t0
     t = torch.tensor([dt_local], dtype=torch.float64)
@@ -610,10 +651,10 @@ def run_slabs(args, S, scenes, torch, rank, world, local_rank, n, box, steps, wa
             "halo_message_bytes": SL.message_bytes(msg_records),
             "halo_message_bytes_allocated": SL.message_bytes(msg_allocated),
             "parallelism": "z-slab x%d, RCCL halo (%s)" % (
-                world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so",
+                world, {"native": "ncclSend/ncclRecv issued by libsph_hip.so: no Python in a step",
                         "host": "host-staged rehearsal",
                         "host-fallback": "HOST-STAGED FALLBACK over gloo: the device-to-device "
-                                         "P2P pre-flight failed on this node"}.get(
+                                         "pre-flights (native RCCL, torch P2P) failed on this node"}.get(
                             mode, "torch.distributed P2P"))}
 
 
@@ -697,14 +738,15 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks": ranks}))
         return
-    # SPH_SLAB_TRANSPORT=host stages the messages through host memory (rehearsal without P2P);
-    # =native lets libsph_hip.so issue the RCCL calls itself (no Python in the step loop)
-    mode = os.environ.get("SPH_SLAB_TRANSPORT", "torch")
-    p2p_ok = True
-    if world > 1 and mode == "torch":
-        # first contact with device-to-device P2P on this node, in a helper process with a time
-        # limit, before this process initialises the GPU
-        p2p_ok = preflight(rank, world)
+    # Which transport carries the halo messages: decided before this process touches the GPU.  The
+    # default process group is gloo - barriers, reductions and every agreement between the ranks use
+    # host tensors and keep working whatever state the device-to-device path is in.
+    mode, preflight_said = "torch", None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        mode, preflight_said = choose_transport(rank, world, torch, dist)
     import smoothed_particle_hydrodynamics_amd as S
     from smoothed_particle_hydrodynamics_amd import scenes
 
@@ -721,16 +763,8 @@ def main():
     parity = None
     fast = args.arithmetic == "fast"
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The default group is gloo: barriers, reductions and every agreement between the ranks
-        # use host tensors and keep working whatever state the device-to-device path is in.  RCCL
-        # gets a group of its own that only the halo exchange uses.
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        verdict = torch.tensor([1 if p2p_ok else 0], dtype=torch.int32)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-        if mode == "torch" and int(verdict.item()) == 0:
-            mode = "host-fallback"     # all ranks alike; the JSON line says so
+        # RCCL gets a group of its own that only torch's halo exchange uses (the native loop has its
+        # own communicator inside libsph_hip.so)
         exchange_group = dist.new_group(backend="nccl") if mode == "torch" else None
         # strong (default): BASELINE configs[3] - 16M particles in the unit box cut in `world`
         # slabs; weak: `world` unit boxes in a row, --particles per GPU
@@ -867,6 +901,8 @@ def main():
         }
         if world > 1:
             line["config"]["halo"] = halo
+            line["config"]["transport"] = mode
+            line["config"]["transport_preflight"] = preflight_said
         if strong_scaling is not None:
             line["strong_scaling"] = strong_scaling
         if other is not None:

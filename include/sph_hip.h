@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPH_HIP_ABI_VERSION 5
+#define SPH_HIP_ABI_VERSION 6
 /* The ABI version the loaded library was built with (compare with SPH_HIP_ABI_VERSION of the
  * header the host was compiled against before calling anything else).  A library built with
  * profiling hooks that cut pieces out of the kernels (diagnostic builds: results are garbage by
@@ -353,15 +353,31 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps);
  * (synchronises): every rank looks at the record counts of the messages it packed last, the
  * largest count * slack + extra_records (at most the capacity given to sph_hip_slab_comm_init)
  * becomes the size every message is packed for, sent and received with from now on
- * (*active_records).  A message that outgrows it raises error bit 2, which stops
- * sph_hip_slab_comm_run: trim again with more head room.  Call after a few steps, and now and
- * then in a long run. */
+ * (*active_records).  sph_hip_slab_comm_run puts the messages back to the allocated size before
+ * they overflow (sph_hip_slab_comm_stats); a message that outgrows even that - or grows by more
+ * than a quarter within 32 steps - raises error bit 2, which stops the run.  Call after a few
+ * steps, and now and then in a long run. */
 int sph_hip_slab_comm_trim(sph_hip_context* ctx, float slack, int extra_records,
                            int32_t* active_records);
 int sph_hip_slab_comm_selftest(sph_hip_context* ctx);
+/* One checked message to and from each neighbour through the same calls (after
+ * sph_hip_slab_comm_init, before the first step; collective over the neighbours; synchronises): a
+ * pre-flight of the device-to-device path that a launcher can run in a helper process with a time
+ * limit before it commits a run to it (bench.py does). */
+int sph_hip_slab_comm_exchange_check(sph_hip_context* ctx);
+/* out[0]: records the messages are currently packed for and transferred with, out[1]: records the
+ * buffers hold, out[2]: how often sph_hip_slab_comm_run put trimmed messages back to the allocated
+ * size (they grow BEFORE they overflow: every 16 steps the ranks reduce the record counts of the
+ * messages they packed last - ncclAllReduce(max) behind the exchange, result read 16 steps later,
+ * at the same step on every rank - and all of them switch together when any message was more than
+ * 4/5 full), out[3]: steps enqueued by sph_hip_slab_comm_run so far. */
+int sph_hip_slab_comm_stats(sph_hip_context* ctx, int32_t out[4]);
 /* Diagnostics (synchronises): live entries, owned particles, error bits (1: a received entry
- * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded,
- * 8: a particle missed the early exchange). */
+ * lies outside the slab and its halo, 2: a message overflowed, 4: context capacity exceeded - by
+ * received records or by the cell counts of a build: the build clamps its ranges to the capacity
+ * and drops what does not fit instead of writing past its arrays, 8: a particle missed the early
+ * exchange, 16: one cell holds a persistent id twice - a record delivered twice, a particle owned
+ * by two slabs). */
 int sph_hip_slab_status(sph_hip_context* ctx, int32_t* live, int32_t* owned, int32_t* errors);
 /* The same error bits without draining the stream: reports what the copy requested by the
  * PREVIOUS call brought (*errors, may be NULL; waits for that one copy if the host has run more

@@ -168,9 +168,15 @@ k_scan_reduce(const uint32_t* __restrict__ count, int ncells, uint32_t* __restri
 // the sum of the totals of the tiles before it (k_scan_reduce wrote them): every workgroup adds
 // them up itself - a few KB out of L2 - instead of waiting for a one-workgroup scan launch of its
 // own between the two kernels.
+// limit = the context's capacity in entries: no cell_start value exceeds it, whatever the counts say.
+// Counts that add up to more than the arrays hold (a slab exchange that delivered records twice, a
+// step that counted its particles twice) then raise error bit 4 - sph_hip_slab_poll_errors /
+// sph_hip_synchronize report SPH_HIP_ERR_EXCHANGE - instead of sending the scatter, the gather and
+// the tile loads of this very step past the end of their arrays.
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restrict__ part,
-             uint32_t* __restrict__ cell_start, uint32_t* __restrict__ big_cells)
+             uint32_t* __restrict__ cell_start, uint32_t* __restrict__ big_cells, uint32_t limit,
+             int32_t* __restrict__ meta)
 {
    if (blockIdx.x == 0 && threadIdx.x == 0) big_cells[0] = 0u;   // k_scatter lists this build's big cells
    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -210,10 +216,10 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
 #pragma unroll
       for (int k = 0; k < SCAN_ITEMS / 4; k++) {
          uint4 q;
-         q.x = run; run += v[4 * k + 0];
-         q.y = run; run += v[4 * k + 1];
-         q.z = run; run += v[4 * k + 2];
-         q.w = run; run += v[4 * k + 3];
+         q.x = min(run, limit); run += v[4 * k + 0];
+         q.y = min(run, limit); run += v[4 * k + 1];
+         q.z = min(run, limit); run += v[4 * k + 2];
+         q.w = min(run, limit); run += v[4 * k + 3];
          o[k] = q;
          // (counts that are zero already - nine cells in ten of a column in a corner of the box -
          // are not written again)
@@ -222,14 +228,17 @@ k_scan_final(uint32_t* __restrict__ count, int ncells, const uint32_t* __restric
    } else {
       for (int k = 0; k < SCAN_ITEMS; k++) {
          if (base + k < ncells) {
-            cell_start[base + k] = run;
+            cell_start[base + k] = min(run, limit);
             if (v[k] != 0u) count[base + k] = 0;
             run += v[k];
          }
       }
    }
    // the thread that owns the last cell also writes the end sentinel
-   if (base <= ncells - 1 && ncells - 1 < base + SCAN_ITEMS) cell_start[ncells] = run;
+   if (base <= ncells - 1 && ncells - 1 < base + SCAN_ITEMS) {
+      cell_start[ncells] = min(run, limit);
+      if (run > limit) atomicOr(&meta[META_ERRORS], 4);
+   }
 }
 
 // ---- 3. scatter -----------------------------------------------------------------------------
@@ -239,7 +248,7 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
           uint32_t* __restrict__ perm, int cells_per_plane, int ncells, int own_lo, int own_hi,
           int sum_lo, int sum_hi, int bnd_lo, int bnd_hi, int32_t* __restrict__ tile_stats,
           int32_t* __restrict__ clear_a, int32_t* __restrict__ clear_b,
-          uint32_t* __restrict__ big_cells)
+          uint32_t* __restrict__ big_cells, uint32_t limit)
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    // tile statistics of the step: the descriptor pass accumulates into them
@@ -249,7 +258,9 @@ k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot,
       const uint32_t c = key[i];
       if (c != (uint32_t)ncells) {   // (the trash cell's entries are dropped: no place, no rank)
          const uint32_t first = cell_start[c], sl = slot[i];
-         perm[first + sl] = (uint32_t)i;
+         // (limit: k_scan_final clamped the cell ranges to the arrays' capacity and raised error bit
+         // 4 when the counts exceed it; what does not fit is dropped here, not written past the end)
+         if (first + sl < limit) perm[first + sl] = (uint32_t)i;
          // the cell's first arrival lists it when it is too crowded for the per-member ranking scan
          if (sl == 0u && cell_start[c + 1] - first > (uint32_t)RANK_BIG)
             big_cells[1u + atomicAdd(&big_cells[0], 1u)] = c;
@@ -342,13 +353,16 @@ rank_gather(int p, int block_p0, uint32_t* __restrict__ lds_id, const uint32_t* 
    const uint32_t b0 = (uint32_t)block_p0;
    const uint32_t b1 = min(b0 + blockDim.x, (uint32_t)n_in);
    const uint32_t in_lo = max(s, b0), in_hi = min(e, b1);   // p itself lies in [in_lo, in_hi)
-   uint32_t rank = 0;
+   uint32_t rank = 0, same = 0;   // same: members of the cell with this very id (the entry itself: 1)
    for (uint32_t q0 = in_lo; q0 < in_hi; q0 += 4) {
       uint32_t other[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) other[u] = lds_id[(q0 + u < in_hi ? q0 + u : in_hi - 1) - b0];
 #pragma unroll
-      for (int u = 0; u < 4; u++) rank += (q0 + u < in_hi && other[u] < id) ? 1u : 0u;
+      for (int u = 0; u < 4; u++) {
+         rank += (q0 + u < in_hi && other[u] < id) ? 1u : 0u;
+         same += (q0 + u < in_hi && other[u] == id) ? 1u : 0u;
+      }
    }
    // what is left of the cell outside this workgroup's positions: [s, in_lo) and [in_hi, e)
 #pragma unroll
@@ -362,9 +376,16 @@ rank_gather(int p, int block_p0, uint32_t* __restrict__ lds_id, const uint32_t* 
 #pragma unroll
          for (int u = 0; u < RANK_UNROLL; u++) other[u] = __float_as_uint(velp_in[other[u]].w);
 #pragma unroll
-         for (int u = 0; u < RANK_UNROLL; u++) rank += (q0 + u < hi && other[u] < id) ? 1u : 0u;
+         for (int u = 0; u < RANK_UNROLL; u++) {
+            rank += (q0 + u < hi && other[u] < id) ? 1u : 0u;
+            same += (q0 + u < hi && other[u] == id) ? 1u : 0u;
+         }
       }
    }
+   // A persistent id held twice by one cell (a halo record delivered twice, a particle two slabs both
+   // think they own): the two would take the same place in the canonical order - one overwriting the
+   // other, one position of the cell keeping whatever an earlier step left there.  Error bit 16.
+   if (same > 1u) atomicOr(const_cast<int32_t*>(&meta[META_ERRORS]), 16);
    posm_out[s + rank] = posm_in[i];
    velp_out[s + rank] = v;
    if (remap) remap[i] = s + rank;   // stand-alone sph_hip_voxelize: where entry i went

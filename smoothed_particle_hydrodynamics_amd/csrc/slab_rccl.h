@@ -92,4 +92,17 @@ struct SlabComm {
    size_t bytes = 0;                  // bytes of a message of active_records
    int32_t* trim_word = nullptr;      // device int: this rank's wish, then the maximum over the ranks
    bool primed = false;               // the first ghosts have been delivered
+   // trimmed messages grow BEFORE they overflow: every GROW_EVERY steps of sph_hip_slab_comm_run the
+   // ranks reduce (max) the record counts of the messages they packed last, the result travels to
+   // pinned host memory behind the exchange, and the look at it - GROW_EVERY steps later, at the same
+   // step on every rank, because every rank holds the same number - decides for all of them alike
+   long long steps_run = 0;           // steps enqueued by sph_hip_slab_comm_run so far
+   int32_t* fill_word = nullptr;      // device int: max records of this rank's two messages, then over the ranks
+   int32_t* fill_host = nullptr;      // pinned copy of it
+   hipEvent_t fill_arrived = nullptr;
+   bool fill_pending = false;
+   int growths = 0;                   // times the messages went back to capacity_records
 };
+#define SLAB_GROW_EVERY 16
+#define SLAB_GROW_FILL_NUM 4          // grow when a message is more than 4/5 full
+#define SLAB_GROW_FILL_DEN 5

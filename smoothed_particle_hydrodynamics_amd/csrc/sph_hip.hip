@@ -130,8 +130,11 @@ void free_all(sph_hip_context* ctx)
          const RcclApi* api = rccl_api(nullptr);
          if (api) (void)api->CommDestroy(c->comm);
       }
-      for (void* q : {c->send_left, c->send_right, c->recv_left, c->recv_right, (void*)c->trim_word})
+      for (void* q : {c->send_left, c->send_right, c->recv_left, c->recv_right, (void*)c->trim_word,
+                      (void*)c->fill_word})
          if (q) (void)hipFree(q);
+      if (c->fill_host) (void)hipHostFree(c->fill_host);
+      if (c->fill_arrived) (void)hipEventDestroy(c->fill_arrived);
       if (c->packed) (void)hipEventDestroy(c->packed);
       if (c->arrived) (void)hipEventDestroy(c->arrived);
       if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -466,7 +469,8 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
                       ncells_scan, ctx->scan_part);
    hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(SCAN_THREADS), 0, st, ctx->cell_count,
-                      ncells_scan, ctx->scan_part, ctx->cell_start, ctx->big_cells);
+                      ncells_scan, ctx->scan_part, ctx->cell_start, ctx->big_cells, (uint32_t)ctx->capacity,
+                      ctx->meta);
    // sorted ranges: owned planes [lo, hi), density planes one wider (clipped to what is held)
    const int own_lo = ctx->plane_lo - g.z0, own_hi = ctx->plane_hi - g.z0;
    const int sum_lo = own_lo - 1 < 0 ? 0 : own_lo - 1;
@@ -479,7 +483,7 @@ int launch_cell_build(sph_hip_context* ctx, void* clear_left = nullptr, void* cl
    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, ctx->key, ctx->slot,
                       ctx->cell_start, ctx->meta, ctx->perm, g.nx * g.ny, g.ncells, own_lo, own_hi,
                       sum_lo, sum_hi, bnd_lo, bnd_hi, ctx->tile_stats, (int32_t*)clear_left,
-                      (int32_t*)clear_right, ctx->big_cells);
+                      (int32_t*)clear_right, ctx->big_cells, (uint32_t)ctx->capacity);
    // crowded cells (listed by k_scatter; none in an ordinary scene: the workgroups then leave at
    // once) are ranked by sorting, behind the per-member scan that skips them; scratch = the
    // staging buffer, idle during a step
@@ -846,7 +850,8 @@ int watch_check(sph_hip_context* ctx, const char* who)
    char text[256];
    snprintf(text, sizeof(text),
             "%s: the slab exchange lost particles, error bits %d (1 entry outside slab and halo, "
-            "2 message overflow, 4 context capacity, 8 missed by the early exchange)", who, (int)bits);
+            "2 message overflow, 4 context capacity, 8 missed by the early exchange, 16 a particle id "
+            "held twice)", who, (int)bits);
    ctx->err = text;
    return SPH_HIP_ERR_EXCHANGE;
 }
@@ -1789,6 +1794,10 @@ int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, i
       SPH_TRY(hipMemsetAsync(*bufs[b], 0, c->bytes, ctx->stream));
    }
    SPH_TRY(hipMalloc((void**)&c->trim_word, sizeof(int32_t)));
+   SPH_TRY(hipMalloc((void**)&c->fill_word, sizeof(int32_t)));
+   SPH_TRY(hipHostMalloc((void**)&c->fill_host, sizeof(int32_t), hipHostMallocDefault));
+   c->fill_host[0] = 0;
+   SPH_TRY(hipEventCreateWithFlags(&c->fill_arrived, hipEventDisableTiming));
    SPH_TRY(hipStreamSynchronize(ctx->stream));
    ncclUniqueId uid;
    memcpy(&uid, id, sizeof(uid));
@@ -1796,7 +1805,53 @@ int sph_hip_slab_comm_init(sph_hip_context* ctx, const void* id, int id_bytes, i
    return SPH_HIP_OK;
 }
 
+// record count of the fuller of a slab's two send messages (their headers' first word)
+__global__ void k_msg_fill(const SlabMsg* __restrict__ left, const SlabMsg* __restrict__ right,
+                           int32_t* __restrict__ out)
+{
+   const int a = left ? left->header[0] : 0, b = right ? right->header[0] : 0;
+   out[0] = a > b ? a : b;
+}
+
 namespace {
+// Trimmed messages (sph_hip_slab_comm_trim) grow before they overflow - an overflow drops records
+// and the run is lost.  Called by every rank at the same steps (every SLAB_GROW_EVERY-th of
+// sph_hip_slab_comm_run, while active < capacity - the same on every rank): look at the reduced
+// fill the PREVIOUS call requested (it waits for that one copy: the exchange it rode behind is
+// SLAB_GROW_EVERY steps old), go back to the allocated size when any rank's message was more than
+// 4/5 full, and request the next one: max over the two send headers -> ncclAllReduce(max) on the
+// exchange stream -> asynchronous copy to pinned memory.  Every rank sees the same number at the
+// same step, so all of them switch together and sender and receiver keep agreeing on the size.
+int comm_grow_if_needed(sph_hip_context* ctx)
+{
+   SlabComm* c = ctx->comm;
+   const RcclApi* api = rccl_api(nullptr);
+   if (c->fill_pending) {
+      SPH_TRY(hipEventSynchronize(c->fill_arrived));
+      c->fill_pending = false;
+      const long long most = c->fill_host[0];
+      if (most * SLAB_GROW_FILL_DEN > (long long)c->active_records * SLAB_GROW_FILL_NUM &&
+          c->active_records < c->capacity_records) {
+         c->active_records = c->capacity_records;
+         c->bytes = sph_hip_slab_message_bytes(c->active_records);
+         c->growths++;
+      }
+   }
+   if (c->active_records >= c->capacity_records || c->nranks < 2) return SPH_HIP_OK;
+   // (the headers are read on the context's stream, where this step's cell build will zero them;
+   // the reduction rides on the exchange stream, in the same place between two exchanges on every rank)
+   hipLaunchKernelGGL(k_msg_fill, dim3(1), dim3(1), 0, ctx->stream, (const SlabMsg*)c->send_left,
+                      (const SlabMsg*)c->send_right, c->fill_word);
+   SPH_TRY(hipGetLastError());
+   SPH_TRY(hipEventRecord(c->packed, ctx->stream));
+   SPH_TRY(hipStreamWaitEvent(c->stream, c->packed, 0));
+   SPH_NCCL_TRY(api->AllReduce(c->fill_word, c->fill_word, 1, ncclInt32, ncclMax, c->comm, c->stream));
+   SPH_TRY(hipMemcpyAsync(c->fill_host, c->fill_word, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+   SPH_TRY(hipEventRecord(c->fill_arrived, c->stream));
+   c->fill_pending = true;
+   return SPH_HIP_OK;
+}
+
 // both directions in one group on the exchange stream
 int comm_send_recv(sph_hip_context* ctx)
 {
@@ -1842,12 +1897,16 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
       // every 16 steps: ask for the device's error word (asynchronous copy) and look at what the
       // previous request brought - a run that lost particles stops within 32 steps, with no
       // synchronisation anywhere
-      if (s % 16 == 0) {
+      // (counted over all calls: a caller that steps one at a time does not wait for a copy per step)
+      if (c->steps_run % 16 == 0) {
          if (ctx->watch_pending) SPH_TRY(hipEventSynchronize(ctx->watch_event));
          ctx->watch_pending = 0;
          if ((rc = watch_check(ctx, "sph_hip_slab_comm_run"))) return rc;
          if ((rc = watch_enqueue(ctx))) return rc;
       }
+      // (the messages packed by the previous step have been sent: their counts decide about growth)
+      if (c->steps_run % SLAB_GROW_EVERY == 0 && (rc = comm_grow_if_needed(ctx))) return rc;
+      c->steps_run++;
       // border planes + messages on the exchange stream, transfer behind them; the interior's
       // acceleration and the integrate meanwhile on the context's stream
       if ((rc = sph_hip_slab_step_begin(ctx, c->send_left, c->send_right, c->active_records, c->stream)))
@@ -1858,9 +1917,10 @@ int sph_hip_slab_comm_run(sph_hip_context* ctx, int steps)
       SPH_TRY(hipStreamWaitEvent(st, c->arrived, 0));
       if ((rc = sph_hip_slab_unpack(ctx, c->recv_left, c->recv_right, c->active_records))) return rc;
    }
-   // the word as it stands after the last step travels behind the loop: the caller's
-   // sph_hip_synchronize (or the next call of this function) reports it
-   return watch_enqueue(ctx);
+   // the word as it stands after the last step travels behind the loop - unless a copy is on its
+   // way already (a caller stepping one at a time): the caller's sph_hip_synchronize, or the next
+   // call of this function, reports it
+   return (steps > 1 || !ctx->watch_pending) ? watch_enqueue(ctx) : SPH_HIP_OK;
 }
 
 int sph_hip_slab_comm_trim(sph_hip_context* ctx, float slack, int extra_records, int32_t* active_records)
@@ -1893,7 +1953,59 @@ int sph_hip_slab_comm_trim(sph_hip_context* ctx, float slack, int extra_records,
    if (want < 1) want = 1;
    c->active_records = want;
    c->bytes = sph_hip_slab_message_bytes(want);
+   c->fill_pending = false;      // (both streams were drained above: a request made for the old size is void)
    if (active_records) *active_records = want;
+   return SPH_HIP_OK;
+}
+
+int sph_hip_slab_comm_stats(sph_hip_context* ctx, int32_t out[4])
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SlabComm* c = ctx->comm;
+   if (!c || !out) {
+      ctx->err = "sph_hip_slab_comm_stats: sph_hip_slab_comm_init first";
+      return SPH_HIP_ERR_INVALID;
+   }
+   out[0] = c->active_records;
+   out[1] = c->capacity_records;
+   out[2] = c->growths;
+   out[3] = (int32_t)(c->steps_run > 0x7fffffffLL ? 0x7fffffffLL : c->steps_run);
+   return SPH_HIP_OK;
+}
+
+// One checked message to and from each neighbour through the calls, the stream and the group shape
+// the exchange uses (before the first step: the message buffers serve as scratch).  Rank r sends
+// bytes of value r + 1 and expects r from the left, r + 2 from the right.
+int sph_hip_slab_comm_exchange_check(sph_hip_context* ctx)
+{
+   int rc = check_ctx(ctx);
+   if (rc) return rc;
+   SlabComm* c = ctx->comm;
+   if (!c || !c->comm || c->primed) {
+      ctx->err = "sph_hip_slab_comm_exchange_check: after sph_hip_slab_comm_init, before the first step";
+      return SPH_HIP_ERR_INVALID;
+   }
+   for (void* q : {c->send_left, c->send_right}) if (q) SPH_TRY(hipMemsetAsync(q, (c->rank + 1) & 0xff, c->bytes, c->stream));
+   for (void* q : {c->recv_left, c->recv_right}) if (q) SPH_TRY(hipMemsetAsync(q, 0, c->bytes, c->stream));
+   if ((rc = comm_send_recv(ctx))) return rc;
+   SPH_TRY(hipStreamSynchronize(c->stream));
+   std::string got(c->bytes, '\0');
+   bool ok = true;
+   for (int side = 0; side < 2; side++) {
+      void* q = side == 0 ? c->recv_left : c->recv_right;
+      if (!q) continue;
+      SPH_TRY(hipMemcpy(&got[0], q, c->bytes, hipMemcpyDeviceToHost));
+      const char want = (char)((side == 0 ? c->rank : c->rank + 2) & 0xff);
+      for (size_t i = 0; i < c->bytes; i++) ok = ok && got[i] == want;
+   }
+   // leave the buffers as sph_hip_slab_comm_init left them
+   for (void* q : {c->send_left, c->send_right, c->recv_left, c->recv_right}) if (q) SPH_TRY(hipMemsetAsync(q, 0, c->bytes, c->stream));
+   SPH_TRY(hipStreamSynchronize(c->stream));
+   if (!ok) {
+      ctx->err = "sph_hip_slab_comm_exchange_check: a neighbour's message arrived with the wrong content";
+      return SPH_HIP_ERR_DEVICE;
+   }
    return SPH_HIP_OK;
 }
 
@@ -1988,8 +2100,10 @@ int sph_hip_synchronize(sph_hip_context* ctx)
    int rc = check_ctx(ctx);
    if (rc) return rc;
    SPH_TRY(hipStreamSynchronize(ctx->stream));
-   if (ctx->had_exchange) {
-      // a slab that exchanges: say so here, where every host waits before it reads results
+   if (ctx->mode == SPH_HIP_MODE_FULL) {
+      // say so here, where every host waits before it reads results: a slab whose exchange lost or
+      // duplicated particles, and any context whose cell build found more entries than it has room
+      // for (bit 4) or an id twice in one cell (bit 16)
       int32_t bits = 0;
       SPH_TRY(hipMemcpy(&bits, ctx->meta + META_ERRORS, sizeof(bits), hipMemcpyDeviceToHost));
       ctx->err_watch[0] = bits;

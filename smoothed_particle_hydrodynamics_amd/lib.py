@@ -113,12 +113,14 @@ PROTOTYPES = {
     "sph_hip_slab_comm_run": (C.c_int, [_ctx, C.c_int]),
     "sph_hip_slab_comm_trim": (C.c_int, [_ctx, C.c_float, C.c_int, _P(C.c_int32)]),
     "sph_hip_slab_comm_selftest": (C.c_int, [_ctx]),
+    "sph_hip_slab_comm_exchange_check": (C.c_int, [_ctx]),
+    "sph_hip_slab_comm_stats": (C.c_int, [_ctx, _P(C.c_int32)]),
     "sph_hip_slab_status": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "sph_hip_slab_poll_errors": (C.c_int, [_ctx, _P(C.c_int32)]),
     "sph_hip_abi_version": (C.c_int, []),
     "sph_hip_selftest_sqrt": (C.c_int, [C.c_int, _P(C.c_uint64), _P(C.c_uint32)]),
 }
-ABI_VERSION = 5   # SPH_HIP_ABI_VERSION of the include/sph_hip.h these prototypes mirror
+ABI_VERSION = 6   # SPH_HIP_ABI_VERSION of the include/sph_hip.h these prototypes mirror
 
 _LIB = None
 

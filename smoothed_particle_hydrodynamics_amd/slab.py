@@ -197,6 +197,18 @@ class HipSlab:
     def comm_selftest(self):
         self._check(self._lib.sph_hip_slab_comm_selftest(self._ctx), "sph_hip_slab_comm_selftest")
 
+    def comm_exchange_check(self):
+        """One checked message to and from each neighbour through the native calls
+        (sph_hip_slab_comm_exchange_check; after comm_init, before the first step)."""
+        self._check(self._lib.sph_hip_slab_comm_exchange_check(self._ctx), "sph_hip_slab_comm_exchange_check")
+
+    def comm_stats(self):
+        """dict: records the messages are transferred with / allocated for, growths, steps run
+        (sph_hip_slab_comm_stats)."""
+        out = (C.c_int32 * 4)()
+        self._check(self._lib.sph_hip_slab_comm_stats(self._ctx, out), "sph_hip_slab_comm_stats")
+        return {"active_records": out[0], "capacity_records": out[1], "growths": out[2], "steps": out[3]}
+
     def synchronize(self):
         self._check(self._lib.sph_hip_synchronize(self._ctx), "sph_hip_synchronize")
 
@@ -396,6 +408,7 @@ class NativeSlabStepper:
             dist.broadcast_object_list(ident, src=0, group=group)
         slab.comm_init(ident[0], rank, world)
         self.slab = slab
+        self.rebalances = 0          # (the native loop keeps its cuts: rebalancing is DistSlabStepper's)
 
     def step(self):
         self.slab.comm_run(1)
@@ -405,6 +418,12 @@ class NativeSlabStepper:
 
     def trim_messages(self, slack=1.25, extra=1024):
         return self.slab.comm_trim(slack, extra)
+
+    @property
+    def message_growths(self):
+        """times the library put trimmed messages back to their allocated size (it does so before
+        they overflow, by itself: sph_hip_slab_comm_stats)"""
+        return self.slab.comm_stats()["growths"]
 
 
 def neighbour_exchange_works(rank, world, device, group=None, nbytes=4096, timeout_s=60.0):

@@ -118,7 +118,37 @@ def test_control_plane_never_uses_the_exchange_group(bench, monkeypatch):
     assert "exchange_group" in src and "control_group=dist.group.WORLD" in src
     main_src = inspect.getsource(bench.main)
     assert 'init_process_group("gloo"' in main_src and 'new_group(backend="nccl")' in main_src
-    assert main_src.index("preflight(rank, world)") < main_src.index("torch.cuda.set_device")
+    # the transport is chosen (helper processes: native RCCL loop -> torch P2P -> host-staged) before
+    # this process touches the GPU, the ranks agreeing over the gloo group between the stages
+    assert main_src.index('init_process_group("gloo"') < main_src.index("choose_transport(rank, world") \
+        < main_src.index("torch.cuda.set_device")
+    choose = inspect.getsource(bench.choose_transport)
+    assert choose.index('"native"') < choose.index('"torch"') and "host-fallback" in choose
+    assert "ReduceOp.MIN" in choose and "group=" not in choose
+
+
+def test_transport_choice_order_and_agreement(bench, monkeypatch):
+    """native -> torch -> host-staged; a 'no' from any stage moves on; SPH_SLAB_TRANSPORT forces one"""
+    import torch
+
+    class FakeDist:
+        class ReduceOp:
+            MIN = "min"
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            return None
+
+    for answers, want in (({"native": True, "torch": True}, "native"),
+                          ({"native": False, "torch": True}, "torch"),
+                          ({"native": False, "torch": False}, "host-fallback")):
+        monkeypatch.delenv("SPH_SLAB_TRANSPORT", raising=False)
+        monkeypatch.setattr(bench, "preflight_stage", lambda kind, rank, world, a=answers: a[kind])
+        mode, said = bench.choose_transport(0, 2, torch, FakeDist)
+        assert mode == want
+        assert said["native"] == answers["native"]
+    monkeypatch.setenv("SPH_SLAB_TRANSPORT", "host")
+    assert bench.choose_transport(0, 2, torch, FakeDist)[0] == "host"
 
 
 def test_source_hash_ignores_comments():

@@ -309,7 +309,11 @@ def test_native_rccl_exchange_single_rank(oracle, hiplib):
         raise
     s.comm_init(ident, 0, 1)
     s.comm_selftest()
-    s.comm_run(3)
+    s.comm_exchange_check()            # (no neighbours: the empty group and the checks around it)
+    s.comm_run(1)
+    s.comm_run(2)                      # one at a time and in a batch: the same loop
+    st = s.comm_stats()
+    assert st == {"active_records": 4096, "capacity_records": 4096, "growths": 0, "steps": 3}, st
     d = s.download()
     assert s.status()["errors"] == 0
     opos, ovel = pos.copy(), vel.copy()
@@ -448,3 +452,64 @@ def test_slab_energies_add_up_when_workgroups_give_up(hiplib, monkeypatch, fused
         assert np.array_equal(got["pos"], part.mPosition) and np.array_equal(got["vel"], part.mVelocity)
     assert ke == pytest.approx(want[0], rel=energy_rtol(mass.size))
     assert pe == pytest.approx(want[1], rel=energy_rtol(mass.size))
+
+
+def test_a_duplicated_halo_record_is_an_error_code_not_a_fault(hiplib):
+    """What a first multi-GPU exchange is most likely to get wrong: a record delivered twice.  The
+    two copies would take the same place in their cell's canonical order (one overwriting the other,
+    one position keeping stale data); the cell build says so - error bit 16 - and the run stops with
+    SPH_HIP_ERR_EXCHANGE instead of stepping on with a corrupted state or faulting."""
+    import torch
+    import smoothed_particle_hydrodynamics_amd as S
+    p, pos, vel, mass = moving_block(20000, unequal=False)
+    group, cuts = build_group(S, p, pos, vel, mass, 2)
+    group.step()
+    a, b = group.slabs
+    for s in group.slabs:
+        s.pack()
+    a.stream.synchronize()
+    # slab 0's message to the right: its first record once more behind the last one
+    msg = a.send_right
+    count = int(msg[:4].view(torch.int32)[0].item())
+    assert 0 < count < a.msg_active
+    header = 8 * 4
+    rec = msg[header:].view(torch.float32).view(-1, 8)
+    rec[count] = rec[0]
+    msg[:4].view(torch.int32)[0] = count + 1
+    group._deliver()
+    for s in group.slabs:
+        s.step()
+    assert b.status()["errors"] & 16
+    with pytest.raises(S.SphHipError, match="lost particles"):
+        b.synchronize()
+    for s in group.slabs:
+        s.close()
+
+
+def test_cell_counts_beyond_the_capacity_are_an_error_code_not_a_fault(hiplib):
+    """Round 3's abort: a step that counted its particles twice sent the next cell build past the end
+    of its arrays.  The build now clamps its ranges to the context's capacity and raises error bit 4.
+    Provoked here the honest way: more records arrive than the slab has room for between its live
+    entries and its capacity - twice, so that the counts of the build exceed the capacity."""
+    import torch
+    import smoothed_particle_hydrodynamics_amd as S
+    from smoothed_particle_hydrodynamics_amd import slab as SL
+    p, pos, vel, mass = moving_block(20000, unequal=False)
+    cuts = SL.plan_cuts(p, pos.reshape(-1, 3)[:, 2], 2)
+    stream = torch.cuda.Stream()
+    slabs = []
+    for r in range(2):
+        own = SL.split_scene(p, cuts, r, pos, vel, mass)
+        # slab 1 has room for its own particles and a handful more: the halo does not fit
+        cap = own[0].size + 64 if r == 1 else 60000
+        s = SL.HipSlab(p, cuts[r], cuts[r + 1], cap, 20000, device=0, has_left=r > 0, has_right=r < 1,
+                       stream=stream)
+        s.upload(*own, all_masses_equal=True)
+        slabs.append(s)
+    group = SL.LocalSlabGroup(slabs)
+    with pytest.raises(S.SphHipError, match="lost particles"):
+        for _ in range(3 * SL.LocalSlabGroup.CHECK_EVERY):
+            group.step()
+    assert slabs[1].status()["errors"] & 4
+    for s in slabs:
+        s.close()
