@@ -553,8 +553,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                count = list_cap + 1;
             }
          }
-#if defined(SPH_ABLATE) && (SPH_ABLATE == 9 || SPH_ABLATE == 12 || SPH_ABLATE == 14)
-         mask = 0u;   // timing only: no lists
+#if defined(SPH_ABLATE) && (SPH_ABLATE == 9 || SPH_ABLATE == 12 || SPH_ABLATE == 14 || SPH_ABLATE == 15)
+         mask = 0u;   // timing only: no lists (15: and no SUM either - tools/valu_census.py)
 #endif
          // append the set bits, ascending, to the lane's neighbour list
          const uint32_t ebase = kbits | (uint32_t)t0;
@@ -644,7 +644,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    for (int j0 = 0; __any(j0 < listed); j0 += DENSITY_UNROLL) {
       TRIP(trips.wave(TRIP_D_SUMTRIPS_W, true);
            for (int u = 0; u < DENSITY_UNROLL; u++) trips.wave(TRIP_D_SUMSLOTS_W, __any(j0 + u < listed));)
-#if !(defined(SPH_ABLATE) && SPH_ABLATE == 1)
+#if !(defined(SPH_ABLATE) && (SPH_ABLATE == 1 || SPH_ABLATE == 15))
       uint32_t entry[DENSITY_UNROLL];
       const int lastw = listed > 0 ? (listed - 1) >> 1 : 0;
 #pragma unroll

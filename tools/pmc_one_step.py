@@ -7,7 +7,9 @@ import smoothed_particle_hydrodynamics_amd as S
 from smoothed_particle_hydrodynamics_amd import scenes
 n = 4*1024*1024
 p, pos, vel, mass = scenes.dam_break(n)
-sph = S.SPH(n, p); sph.setParticles(pos, vel, mass)
+# SPH_PMC_MODE=fast: the tolerance-mode arithmetic (bench.py's headline)
+sph = S.SPH(n, p, mode=S.MODE_FULL_FAST if os.environ.get("SPH_PMC_MODE") == "fast" else S.MODE_FULL)
+sph.setParticles(pos, vel, mass)
 sph.setTiming(S.TIMING_OFF)
 for _ in range(3):
     sph.step()
