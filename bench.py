@@ -334,12 +334,12 @@ def reference_scene(S, steps=8, n=32768):
 
 # (tools/profile_round.sh points these at the files it has just written under gpurun_out/, which are
 # then committed under profiles/ with the same names)
-PROFILE = os.environ.get("SPH_BENCH_COUNTERS") or os.path.join(ROOT, "profiles", "r3_kernel_counters.json")
+PROFILE = os.environ.get("SPH_BENCH_COUNTERS") or os.path.join(ROOT, "profiles", "r4_kernel_counters.json")
 
 
 def kernel_counters(n, arithmetic="fast"):
     """What the committed counter passes say about the density + acceleration launch pair
-    (tools/profile_round.sh -> profiles/r3_kernel_counters.json, one entry per arithmetic): HBM bytes (rocprofv3 --pmc
+    (tools/profile_round.sh -> profiles/r4_kernel_counters.json, one entry per arithmetic): HBM bytes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled as the gfx950 guide prescribes) and
     VALU wave-instructions (SQ_INSTS_VALU).  The file carries the hash of the kernel sources it
     was measured on: (None, reason) when that is not the code being run, or the workload differs."""
@@ -360,60 +360,46 @@ def kernel_counters(n, arithmetic="fast"):
         os.path.basename(PROFILE).replace("r3a_", "r3_"), arithmetic, prof["csrc_sha16"])
 
 
-PRICES = os.environ.get("SPH_BENCH_PRICES") or os.path.join(ROOT, "profiles", "r3_valu_prices.json")
+CENSUS = os.environ.get("SPH_BENCH_CENSUS") or os.path.join(ROOT, "profiles", "r4_valu_census.json")
 
 
-def valu_issue(prof, pair_ms):
-    """What share of the SIMDs' cycles the pair's VALU instructions book - the bound that is real
-    for this pass.  Three figures:
-      flat4  every VALU wave-instruction at 4 cycles: the SQ's own accounting (SQ_ACTIVE_INST_VALU
-             books one quad-cycle for a 2- and a 4-cycle instruction alike, two for a
-             transcendental, four for v_rcp_f64: profiles/r3_kernel_counters.json,
-             ubench_counter_calibration) - round 2's figure;
-      low / high  the counted classes at the prices tools/ubench/valu3.hip measured with every SIMD
-             saturated (profiles/r3_valu_prices.json, cycles at the clock the chip held): plain
-             fp32 / int32 adds, multiplies, fused multiply-adds and moves 2.24 - MI355X_MICROARCH.md
-             says 2; the difference is the loop's own scalar instructions - packed fp32,
-             v_alignbit / v_bfe / v_lshl_or / v_ffbl / v_cmp / v_cndmask and fp64 4.1-4.3,
-             transcendentals 8.1, v_rcp_f64 16.2.  The class counters do not tell a packed fp32
-             operation from a plain one, nor the 4-cycle integer forms from the 2-cycle ones (same
-             calibration): `low` prices every such instruction at the plain rate, `high` at the wide
-             one; the truth lies between (TEST's distance arithmetic is packed, the pair arithmetic
-             is not)."""
-    insts = prof.get("valu_wave_instructions_per_launch_pair")
-    if not insts:
-        return None
+def valu_issue(prof, pair_ms, arithmetic="fast"):
+    """What share of the SIMDs' issue cycles the pair's VALU instructions book - the bound that is real
+    for this pass - as ONE number, from the committed census
+    (tools/valu_census.py -> profiles/r4_valu_census.{md,json}):
+      * wave-instructions per phase: SQ_INSTS_VALU of the shipped kernels and of builds with one phase
+        cut out (TEST / per-chunk bookkeeping / append / SUM / pair loops / prologues);
+      * the opcode mix of each phase from the line tables of the shipped ISA;
+      * a measured price for every opcode (tools/ubench/valu3.hip, valu5.hip: every SIMD saturated,
+        8 waves per SIMD; plain 2.24 cycles, packed / compare / select / shift-left / min-max 4.1-4.2,
+        transcendental 8.1).
+    frac = 64 waves per SIMD x priced issue cycles per wave / (pair duration x shader clock).  The
+    prices are additive - a wave's wide-class and plain instructions are charged as if they never
+    overlapped - so the figure is an upper estimate of the port's occupancy; what is left to 1 is time
+    the VALU port idles (dependent chains of sparse loops, LDS and memory latency, barriers).  None
+    when the census was taken on other kernel sources or covers another arithmetic."""
+    from smoothed_particle_hydrodynamics_amd.build import source_hash
     try:
-        table = json.load(open(PRICES))["instructions"]
-        price = lambda name: table[name]["cycles"][3]          # 8 waves per SIMD
-        plain = (price("v_fma_f32") + price("v_add_f32") + price("v_add_u32")) / 3.0
-        wide = (price("v_pk_fma_f32") + price("v_alignbit_b32") + price("v_cmp + v_cndmask")) / 3.0
-        trans, f64, rcp64 = price("v_rcp_f32"), price("v_fma_f64"), price("v_rcp_f64")
-        ghz = sorted(table[n]["ghz"][3] for n in table)
-        # the clock the pair kernels themselves held in the counter pass (GRBM_GUI_ACTIVE / 8 / the
-        # dispatch's duration), else the median of the microbenchmark's runs
-        clock = prof.get("shader_clock_ghz_while_profiled") or ghz[len(ghz) // 2]
-    except (OSError, KeyError, ValueError):
-        return {"wave_instructions_per_launch_pair": insts, "note": "no price table (profiles/r3_valu_prices.json)"}
-    cls = lambda name: prof.get("SQ_INSTS_VALU_" + name, 0.0)
-    f32 = cls("ADD_F32") + cls("MUL_F32") + cls("FMA_F32")
-    f64n = cls("ADD_F64") + cls("MUL_F64") + cls("FMA_F64") + cls("INT64")
-    other = insts - f32 - f64n - cls("TRANS_F32") - cls("TRANS_F64")     # int32, cvt, moves, logic, selects
-    fixed = cls("TRANS_F32") * trans + cls("TRANS_F64") * rcp64 + f64n * f64
-    simd_cycles = 1024.0 * pair_ms * 1e-3 * clock * 1e9
-    return {"wave_instructions_per_launch_pair": insts,
-            "classes": {"fp32_add_mul_fma": f32, "fp64_and_int64": f64n, "trans_f32": cls("TRANS_F32"),
-                        "trans_f64": cls("TRANS_F64"), "int32_moves_logic_selects": other},
-            "cycles_per_wave_instruction": {"plain": plain, "wide": wide, "trans_f32": trans, "fp64": f64,
-                                            "rcp_f64": rcp64},
-            "simds": 1024, "clock_ghz": clock,
-            "frac_low": ((f32 + other) * plain + fixed) / simd_cycles,
-            "frac_high": ((f32 + other) * wide + fixed) / simd_cycles,
-            "frac_flat4": insts * 4.0 / simd_cycles,
-            "note": "share of the SIMDs' issue cycles the pair's VALU instructions book, at the clock "
-                    "the pair kernels held in the counter pass (GRBM_GUI_ACTIVE): low / high = the "
-                    "instructions the counters cannot classify as plain or wide at either price; "
-                    "flat4 = the SQ's own accounting (round 2's figure).  See valu_issue() in bench.py"}
+        census = json.load(open(CENSUS))
+    except (OSError, ValueError):
+        return None
+    if census.get("csrc_sha16") != source_hash() or census.get("arithmetic") != arithmetic:
+        return {"frac": None, "note": "the committed census (%s, %s arithmetic) does not describe the kernels being "
+                                      "run (%s): re-run tools/pmc_census.sh + tools/valu_census.py" % (
+                                          census.get("csrc_sha16"), census.get("arithmetic"), source_hash())}
+    clock = (prof or {}).get("shader_clock_ghz_while_profiled") or census["ghz"]
+    cycles = census["pair"]["issue_cycles_per_simd"]
+    have = pair_ms * 1e-3 * clock * 1e9
+    return {"frac": cycles / have,
+            "issue_cycles_per_simd_per_launch_pair": cycles,
+            "simd_cycles_per_launch_pair": have, "clock_ghz": clock, "simds": 1024,
+            "wave_instructions_per_launch_pair": census["pair"]["wave_instructions_per_launch_pair"],
+            "not_fp32_arithmetic_per_launch_pair": census["pair"]["non_arithmetic_per_launch_pair"],
+            "by_phase": [{"phase": ph["phase"], "wave_instructions_per_wave": round(ph["wave_instructions_per_wave"], 1),
+                          "issue_cycles_per_wave": round(ph["issue_cycles_per_wave"], 1)} for ph in census["phases"]],
+            "residual": "attributed wave-instructions = SQ_INSTS_VALU exactly (phases are differences of builds); "
+                        "1 - frac = issue cycles the VALU port idles",
+            "source": "profiles/%s (kernel sources %s)" % (os.path.basename(CENSUS), census["csrc_sha16"])}
 
 
 def phase_split(ctx, S, step, synchronize, set_timing, phase_totals, steps=5):
@@ -825,7 +811,7 @@ def main():
         df_ms = totals["pair_ms"]
         achieved = DENSITY_FORCE_BYTES * n_rank / (df_ms * 1e-3) / 1e9
         prof, prof_note = kernel_counters(n, args.arithmetic) if world == 1 else (None, "1-GPU profile only")
-        valu = valu_issue(prof, df_ms) if prof is not None else None
+        valu = valu_issue(prof, df_ms, args.arithmetic) if world == 1 else None
         traffic = prof["density_plus_acceleration_hbm_bytes"] if prof else None
         scaling = args.scaling if world > 1 else "weak"
         line = {

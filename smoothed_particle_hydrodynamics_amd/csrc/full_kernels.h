@@ -71,7 +71,7 @@ __device__ __forceinline__ void density_untiled(int p, const float4* __restrict_
             {
                float d = sqrtf(d2);
                if (!UNIT_SCALE) d *= k.sim_scale;
-               density_accumulate(k, pj.w, d, density);
+               density_accumulate<UNIT_SCALE>(k, pj.w, d, density);
             }
             count++;
          }

@@ -624,7 +624,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                {
                   float d = sqrt_rn(d2);
                   if (!UNIT_SCALE) d *= k.sim_scale;
-                  density_accumulate(k, mj, d, density);
+                  density_accumulate<UNIT_SCALE>(k, mj, d, density);
                }
                count++;
             }
@@ -666,7 +666,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                {
                   float d = sqrt_rn(d2);
                   if (!UNIT_SCALE) d *= k.sim_scale;
-                  density_accumulate(k, mj, d, density);
+                  density_accumulate<UNIT_SCALE>(k, mj, d, density);
                }
                if (kept != j0 + u) my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry[u];
                kept++;
@@ -860,7 +860,7 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                         if (d2 < k.h2) {
                            float d = sqrt_rn(d2);
                            if (!UNIT_SCALE) d *= k.sim_scale;
-                           density_accumulate(k, mj, d, density);
+                           density_accumulate<UNIT_SCALE>(k, mj, d, density);
                            if (kept != j0 + u)
                               my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry[u];
                            kept++;
@@ -1311,7 +1311,11 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       // (A lane past its count relies on 0 * A = 0.  A = p_i * rhoiInv^2 is not finite when p_i is a
       // positive subnormal (1 / p_i = inf), and 0 * inf would poison a sum the list-walking routes leave
       // untouched: a wave holding such a lane - never seen outside a test - selects the factor instead.)
-      const bool odd_lane = __any(!__builtin_isfinite(s.pi_div_rhoi2));
+      // (... and the lane itself as a neighbour must yield a FINITE factor, so that its r = 0 makes the
+      // term vanish whatever the factor is: then a lane past its count needs no select on m B - a
+      // compare and two selects per pair were 12 of the pair's ~140 issue cycles)
+      const float self_c = (k.hscaled * k.hscaled) * (s.pi_div_rhoi2 * xyzc[self_tile].w);
+      const bool odd_lane = __any(!__builtin_isfinite(s.pi_div_rhoi2) || !__builtin_isfinite(self_c));
       TRIP(TripCounters trips; trips.wave(TRIP_A_WAVES - 16, true); trips.lane(TRIP_A_CNT_L - 16, (unsigned)cnt);
            trips.lane(TRIP_A_LANES_L - 16, live ? 1u : 0u); trips.lane(TRIP_A_NV_L - 16, (unsigned)(cnt - first_v));)
       for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
@@ -1333,7 +1337,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
             const bool valid = j0 + u < cnt;
             const float4 pj = xyzc[valid ? ListEntry<WIDE>::tile(entry[u]) : self_tile];
             dd[u] = dist2(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, dx[u], dy[u], dz[u]);
-            bm[u] = valid ? pj.w : 0.0f;
+            bm[u] = pj.w;      // (a lane past its count: its own m B, with r = 0 exactly - see odd_lane)
          }
 #if defined(SPH_ABLATE) && SPH_ABLATE == 22
 #pragma unroll

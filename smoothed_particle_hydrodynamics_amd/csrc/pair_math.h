@@ -8,10 +8,15 @@
 #include "sph_device.h"
 
 // computeDensity's inner term (reference src/sph.cpp:744-761).  d is the stored distance.
+// INSIDE: the caller has established d <= hscaled, so the reference's range test (:746) cannot fail
+// and is not evaluated - the FULL-mode sums with unit simulation scale: d = sqrt_rn(d2) of a pair
+// that passed d2 < h2, the root is monotone and the host selects those instantiations only when
+// sqrtf(h2) <= hscaled (unit_scale() in sph_hip.hip).  A compare and a select per neighbour less.
+template <bool INSIDE = false>
 __device__ __forceinline__ void density_accumulate(const PairConsts& k, float mass, float d,
                                                    float& density)
 {
-   if (!(d > k.hscaled)) {
+   if (INSIDE || !(d > k.hscaled)) {
       float t = (k.hscaled2 - (d * d));
       t = (t * t * t);
       const float w = k.kernel1 * t;

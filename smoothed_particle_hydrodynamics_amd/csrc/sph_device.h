@@ -304,7 +304,12 @@ __device__ __forceinline__ float sqrt_rn(float x)
 {
    // bits in [1, 0x0c7fffff]  <=>  0 < x < 2^-102  (x is never negative here; -0 and 0 pass)
    if (__builtin_expect(__any(__float_as_uint(x) - 1u < 0x0c7fffffu), 0)) return sqrtf(x);
-   const float y = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));
+   // (seed of x + FLT_MIN, one plain addition, instead of max(x, FLT_MIN), which costs two wide-class
+   // v_max_f32 - profiles/r4_valu_prices_more.txt: here x is 0 or at least 2^-102, so the sum is
+   // FLT_MIN for 0 and x itself otherwise - except for odd mantissas in [2^-102, 2^-101), a tie that
+   // moves the SEED's argument by one ulp; the result is checked for every float all the same:
+   // sph_hip_selftest_sqrt)
+   const float y = __builtin_amdgcn_rsqf(x + 1.17549435e-38f);
    float g = x * y;
    float h = 0.5f * y;
    const float r = __builtin_fmaf(-h, g, 0.5f);
@@ -332,7 +337,7 @@ __device__ __forceinline__ void sqrt_rn_batch(float (&x)[N])
    }
 #pragma unroll
    for (int u = 0; u < N; u++) {
-      const float y = __builtin_amdgcn_rsqf(fmaxf(x[u], 1.17549435e-38f));
+      const float y = __builtin_amdgcn_rsqf(x[u] + 1.17549435e-38f);      // (as in sqrt_rn)
       float g = x[u] * y;
       float h = 0.5f * y;
       const float r = __builtin_fmaf(-h, g, 0.5f);

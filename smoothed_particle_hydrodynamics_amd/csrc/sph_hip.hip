@@ -91,7 +91,15 @@ PairConsts pair_consts(const sph_hip_params& p, bool fast)
    return k;
 }
 
-bool unit_scale(const sph_hip_params& p) { return p.sim_scale == 1.0f && p.sim_scale_inv == 1.0f; }
+// The kernels' UNIT_SCALE instantiations: mSimulationScale = 1 (no multiplication by it) and - what
+// lets the FULL-mode density sums drop the reference's "d > hscaled" test for pairs that passed
+// d2 < h2 (pair_math.h: density_accumulate<INSIDE>) - a smoothing length whose constants agree:
+// sqrtf(h2) <= hscaled.  Parameters that do not (a caller may set any) take the general
+// instantiations, which multiply by a scale of 1.0: the same bits.
+bool unit_scale(const sph_hip_params& p)
+{
+   return p.sim_scale == 1.0f && p.sim_scale_inv == 1.0f && sqrtf(p.h2) <= p.hscaled;
+}
 
 // environment switch "NAME=1", read once per name
 bool getenv_flag(const char* name)

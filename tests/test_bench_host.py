@@ -58,13 +58,18 @@ def test_counter_profile_is_only_used_for_the_code_it_was_taken_on(bench, tmp_pa
 
 
 def test_committed_counter_profile_matches_the_committed_kernels(bench):
-    """profiles/r3_kernel_counters.json must describe the kernel sources in this tree - otherwise
-    the driver's bench line silently loses roofline.traffic."""
+    """profiles/r4_kernel_counters.json and r4_valu_census.json must describe the kernel sources in
+    this tree - otherwise the driver's bench line silently loses roofline.traffic / roofline.valu."""
     for arithmetic in ("fast", "exact"):
         prof, why = bench.kernel_counters(4 * 1024 * 1024, arithmetic)
         assert prof is not None, why
         assert 1.0e9 < prof["density_plus_acceleration_hbm_bytes"] < 4.0e9
         assert 2.0e8 < prof["valu_wave_instructions_per_launch_pair"] < 1.0e9
+    valu = bench.valu_issue({}, 0.80, "fast")
+    assert valu is not None and valu["frac"] is not None, valu
+    assert 0.5 < valu["frac"] <= 1.0, valu["frac"]            # one number, and a bound
+    assert sum(ph["wave_instructions_per_wave"] for ph in valu["by_phase"]) * 65536 == pytest.approx(
+        valu["wave_instructions_per_launch_pair"], rel=1e-6)
 
 
 def test_gpus_n_without_world_size_becomes_the_launcher(bench, monkeypatch):

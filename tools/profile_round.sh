@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence run for one round, on the GPU box:  bash tools/profile_round.sh r3
+# Evidence run for one round, on the GPU box:  bash tools/profile_round.sh r4
 # Writes under gpurun_out/<tag>_*; tools/pmc_summary.py then turns the counter CSVs into
 # gpurun_out/<tag>_kernel_counters.json (stamped with the hash of the kernel sources); that file,
 # the kernel-stats CSV and the microbenchmark's price table are copied to profiles/ by hand.
@@ -9,7 +9,7 @@
 # one pass yields the counters of the exact and the tolerance-mode kernels (the template argument
 # in the kernel name tells them apart).
 set -eo pipefail
-tag=${1:-r3}
+tag=${1:-r4}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp

@@ -260,7 +260,12 @@ def main():
         t[1] += n * cyc_per
         t[2] += n * (1.0 - arith)
     waves_per_simd = 65536.0 / 1024.0
-    out = {"source": "tools/valu_census.py", "ghz": a.ghz, "phases": [], "kernels": {}}
+    sys.path.insert(0, ROOT)
+    from smoothed_particle_hydrodynamics_amd.build import source_hash
+    out = {"source": "tools/valu_census.py: SQ_INSTS_VALU per phase (ablated builds) x opcode mix (line tables of "
+                     "the shipped ISA) x price per opcode (tools/ubench/valu3.hip, valu5.hip)",
+           "csrc_sha16": source_hash(), "particles": 4 * 1024 * 1024, "arithmetic": "fast", "ghz": a.ghz,
+           "phases": [], "kernels": {}}
     print("# VALU census of the density + acceleration pair, 4M-particle column, tolerance-mode arithmetic\n")
     print(__doc__.split("\n\n")[1].replace("\n", " ") + "\n")
     print("| phase | wave-instructions per wave | cycles per instruction (priced mix) | issue cycles per wave | fp32 arithmetic | wide-class opcodes | static instructions attributed | largest opcodes |")
