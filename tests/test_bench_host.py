@@ -69,7 +69,7 @@ def test_committed_counter_profile_matches_the_committed_kernels(bench):
     assert valu is not None and valu["frac"] is not None, valu
     assert 0.5 < valu["frac"] <= 1.0, valu["frac"]            # one number, and a bound
     assert sum(ph["wave_instructions_per_wave"] for ph in valu["by_phase"]) * 65536 == pytest.approx(
-        valu["wave_instructions_per_launch_pair"], rel=1e-6)
+        valu["wave_instructions_per_launch_pair"], rel=1e-3)      # (phases are rounded to 0.1 in the line)
 
 
 def test_gpus_n_without_world_size_becomes_the_launcher(bench, monkeypatch):
