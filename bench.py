@@ -11,7 +11,7 @@ FULL neighbour mode) over the whole particle set, state resident in HBM.  Prints
 line (rank 0).  N = 1: the 4 194 304-particle column (BASELINE configs[2]).  N > 1: strong
 scaling of the 16 777 216-particle column (configs[3]) over N z-slabs, with rank 0's
 single-context time of the same scene (`strong_scaling`) and the 67 108 864-particle 8:1:1
-channel (configs[4]) as `other_scaling`.  See DESIGN.md §Measurement for the definitions used
+channel (configs[4]) as `other_scaling`.  See DESIGN.md §7 for the definitions used
 in `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -365,7 +365,7 @@ CENSUS = os.environ.get("SPH_BENCH_CENSUS") or os.path.join(ROOT, "profiles", "r
 
 def valu_issue(prof, pair_ms, arithmetic="fast"):
     """What share of the SIMDs' issue cycles the pair's VALU instructions book - the bound that is real
-    for this pass (DESIGN.md 3.2) - as ONE number, from the committed census
+    for this pass (DESIGN.md 5) - as ONE number, from the committed census
     (tools/valu_census.py -> profiles/r4_valu_census.{md,json}):
       * wave-instructions per phase: SQ_INSTS_VALU of the shipped kernels and of builds with one phase
         cut out (TEST / per-chunk bookkeeping / append / SUM / pair loops / prologues);

@@ -61,9 +61,18 @@ typedef enum sph_hip_status {
  *          accumulation, and a viscous sum that leaves out the neighbours whose weight - the
  *          rescale of src/sph.cpp:880-882 applied once per later neighbour - is below 1e-20;
  *          both sums on the reference's stored distance.  Neighbour counts AND densities are
- *          identical to FULL; accelerations agree to 1e-4 relative (vector norm; measured 6e-6
- *          on the 4M column); deterministic,
- *          the same for any route and slab count, not bit-reproducible against the CPU. */
+ *          identical to FULL; the acceleration of EVERY particle agrees with the IEEE evaluation of
+ *          src/sph.cpp to 1e-4 relative, |a - a_ref| <= 1e-4 * max(|a|, |a_ref|) (vector norm) -
+ *          asserted as written, without escape clauses, on every BASELINE configuration and every
+ *          committed scene (tests/test_gpu_full_fast.py, test_gpu_full_size.py, test_gpu_c4_c5.py;
+ *          measured: 1.4e-5 at worst on the 4M column at rest, 6e-6 moving; bench.py re-checks the
+ *          state it timed: `parity` in its JSON line).  ONE clause exists, for adversarial inputs only
+ *          (tests/test_gpu_random_scenes.py, which prints every particle that takes it): where a
+ *          particle's ~30 pair terms cancel to less than a hundredth of their magnitude sum T, any
+ *          evaluation that is not the reference's bit for bit - its own -ffast-math build included -
+ *          differs by rounding errors of the terms, and such a particle is held to 1e-6 * T instead
+ *          (at most 0.5 % of a scene's particles).  Deterministic, the same for any route and slab
+ *          count, not bit-reproducible against the CPU. */
 typedef enum sph_hip_mode {
    SPH_HIP_MODE_REF = 0,
    SPH_HIP_MODE_FULL = 1,

@@ -12,9 +12,10 @@
 //   * step() runs the five phases on the GPU and emits the same two signals.  The host mirrors
 //     the GUI reads at frame rate without locks (Particle arrays through getParticles(),
 //     per-voxel QList sizes through getGrid(); reference src/visualization.cpp:144-158, 178-193)
-//     are DOUBLE-BUFFERED: step() asks the library for an asynchronous snapshot into the back
-//     `Particle` (page-locked, copied on a separate stream: sph_hip_download_async) and returns
-//     without waiting for it; a later step() finds it complete and swaps it in.  The solver never
+//     are TRIPLE-BUFFERED (front / retired / back: a frame that still holds the previous pointer
+//     never reads a buffer being filled): step() asks the library for an asynchronous snapshot
+//     into the back `Particle` (page-locked, copied on a separate stream: sph_hip_download_async)
+//     and returns without waiting for it; a later step() finds it complete and swaps it in.  The solver never
 //     stalls on PCIe, the GUI always sees one complete state at most a frame or two old - in both
 //     neighbour modes (the occupancy comes on the reference's voxel grid in FULL mode too).
 //     SPH_DROPIN_SYNC_MIRROR=1 (or sph_dropin_sync_mirror() before reading) gives the blocking

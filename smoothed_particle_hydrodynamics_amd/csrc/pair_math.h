@@ -232,7 +232,7 @@ __device__ __forceinline__ void accel_pair_fast_viscous(const PairConsts& k, Acc
 // of them when |s| >= 1/2.  What is left out is at most 1e-20 of the largest viscous term of the
 // particle - against a tolerance of 1e-4 on the acceleration - and the neighbours that are left
 // out need neither their velocity nor their C: the only per-neighbour gather of the acceleration
-// pass shrinks from ~31 to ~4 per particle (it was the pass's floor: DESIGN.md 3.2).
+// pass shrinks from ~31 to ~4 per particle (it was the pass's floor: profiles/design_history_r1_r3.md 3.2).
 __device__ __forceinline__ int visc_keep(float visc_scale)
 {
    const float a = __builtin_fabsf(visc_scale);

@@ -1,5 +1,5 @@
 """Timeline of a dam that actually breaks (apply_gravity + apply_walls, 4M particles): step time,
-phase split, neighbour counts, tile statistics every 51 steps (DESIGN.md section 5)."""
+phase split, neighbour counts, tile statistics every 51 steps (DESIGN.md section 4.3)."""
 import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import smoothed_particle_hydrodynamics_amd as S

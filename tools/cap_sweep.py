@@ -1,6 +1,6 @@
 """Density / acceleration phase time of the 4M-particle column with the LDS tile capacity pinned
 (SPH_HIP_TILE_CAP) from 2016 to 2752 entries: the steps in the times are the capacities at which a
-pass loses a workgroup per CU, i.e. the LDS allocation granularity of the device (DESIGN.md 3,
+pass loses a workgroup per CU, i.e. the LDS allocation granularity of the device (DESIGN.md 4.1,
 csrc/sph_hip.hip tile_levels).  One process per capacity."""
 import sys, time, os, subprocess
 if os.environ.get("CAP_SWEEP_CHILD"):

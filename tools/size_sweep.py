@@ -1,5 +1,5 @@
 """sph_hip_run wall time per step of the dam-break column at several sizes on one GPU
-(DESIGN.md section 5):  python tools/size_sweep.py [sizes...]"""
+(profiles/design_history_r1_r3.md section 5):  python tools/size_sweep.py [sizes...]"""
 import os
 import sys
 import time

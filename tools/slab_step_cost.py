@@ -1,7 +1,7 @@
 """What a slab step costs next to the single context, without a second GPU: `world` logical slabs
 of an n-particle dam-break take turns on this GPU (LocalSlabGroup: messages handed over by pointer,
 early exchange on a second stream unless `serial` is given), then the same scene steps in one
-context (DESIGN.md section 6).
+context (DESIGN.md section 8).
 
     python tools/slab_step_cost.py 16777216 8 [serial]
 """
