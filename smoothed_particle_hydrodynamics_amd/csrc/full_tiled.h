@@ -91,19 +91,76 @@ struct TripCounters {
 #ifndef ACCEL_BLOCKS
 #define ACCEL_BLOCKS (TILE_THREADS == 256 ? 5 : 2)
 #endif
-// Neighbour lists handed from the density pass to the acceleration pass: per workgroup
-// list_rows(list_cap) rows of 256 32-bit words (row r = every lane's entries 2r and 2r+1, so a wave
-// reads/writes 256 contiguous bytes).  Only rows in use are ever touched.  list_cap - the
-// neighbours per particle the lists hold - is a launch argument: a context starts with NLIST_CAP
-// and the host doubles it (up to NLIST_CAP_MAX, memory permitting) when the density pass reports
-// particles that went without a list; a breaking dam compresses to several hundred neighbours.
+// Neighbour lists handed from the density pass to the acceleration pass, 16-bit entries, per
+// workgroup a block of list_rows(list_cap) * TILE_THREADS 32-bit words laid out in BLOCKS OF EIGHT
+// ENTRIES: entries 8b .. 8b+7 of lane t are the 16 bytes at b * LIST_BLOCK_BYTES + 16 t.  A consumer
+// fetches a trip's eight entries with one 16-byte load per lane (a wave: 1 KB contiguous); the
+// producer fills a 16-byte slot with eight consecutive 2-byte stores of ONE lane, so a 128-byte
+// line is complete after eight lanes have taken eight pops each and leaves the L2 whole.  (Until
+// round 4 entry j sat in half (j & 1) of word (j >> 1) * TILE_THREADS + t: a line was shared by 32
+// lanes x 2 entries and stayed open until the slowest of them got there - in a compressed scene,
+// 150 entries per particle and three workgroups per CU, the open lines outgrew the L2 several
+// times over and the density pass WROTE 9 GB for 1.3 GB of entries: profiles/r4_notes.md.)
+// Only blocks in use are ever touched.  list_cap - the neighbours per particle the lists hold - is a
+// launch argument: a context starts with NLIST_CAP and the host enlarges it (up to NLIST_CAP_MAX,
+// memory permitting) when the density pass reports particles that went without a list.
 #ifndef NLIST_CAP
 #define NLIST_CAP 254
 #endif
 #define NLIST_CAP_MAX 1022
-// two entries per 32-bit word: word r of a lane holds its entries 2r (low half) and 2r+1
-// (+ one spare row)
-__host__ __device__ __forceinline__ constexpr int list_rows(int list_cap) { return list_cap / 2 + 1; }
+#define LIST_BLOCK_ENTRIES 8
+#define LIST_BLOCK_BYTES (16 * TILE_THREADS)
+// rows of TILE_THREADS words a workgroup's list block takes: whole blocks for entries 0 .. list_cap
+__host__ __device__ __forceinline__ constexpr int list_rows(int list_cap)
+{
+   return 4 * ((list_cap + LIST_BLOCK_ENTRIES) / LIST_BLOCK_ENTRIES);
+}
+// byte offset of entry j of the lane whose slots start at lane_off (= 16 * lane) in the block
+__device__ __forceinline__ uint32_t list_entry_off(uint32_t j, uint32_t lane_off)
+{
+   return (j >> 3) * (uint32_t)LIST_BLOCK_BYTES + lane_off + (j & 7u) * 2u;
+}
+// The append's running position.  pos holds block and slot of the next entry with the lane field
+// (bits 4 .. 4 + log2(TILE_THREADS)) ALL ONES: pos += 2 then carries from the slot field straight
+// into the block field when a 16-byte slot is full (and leaves the lane field zero: or it back).
+// The address puts the lane in: one v_bfi.  Three instructions per entry, none of them a shift.
+#define LIST_LANE_FIELD ((uint32_t)(LIST_BLOCK_BYTES - 16))
+__device__ __forceinline__ uint32_t list_pos_of(uint32_t j)
+{
+   return ((j >> 3) * (uint32_t)LIST_BLOCK_BYTES + (j & 7u) * 2u) | LIST_LANE_FIELD;
+}
+__device__ __forceinline__ uint32_t list_pos_off(uint32_t pos, uint32_t lane_off)
+{
+   return (LIST_LANE_FIELD & lane_off) | (~LIST_LANE_FIELD & pos);      // v_bfi_b32
+}
+__device__ __forceinline__ uint32_t list_pos_next(uint32_t pos) { return (pos + 2u) | LIST_LANE_FIELD; }
+__device__ __forceinline__ uint32_t list_entry_load(const char* __restrict__ lists, uint32_t j, uint32_t lane_off)
+{
+   return *reinterpret_cast<const uint16_t*>(lists + list_entry_off(j, lane_off));
+}
+// the eight entries of block b of that lane
+__device__ __forceinline__ uint4 list_block_load(const char* __restrict__ lists, int b, uint32_t lane_off)
+{
+   return *reinterpret_cast<const uint4*>(lists + (uint32_t)b * (uint32_t)LIST_BLOCK_BYTES + lane_off);
+}
+__device__ __forceinline__ void list_block_entries(const uint4& blk, uint32_t (&entry)[8])
+{
+   entry[0] = blk.x & 0xffffu; entry[1] = blk.x >> 16;
+   entry[2] = blk.y & 0xffffu; entry[3] = blk.y >> 16;
+   entry[4] = blk.z & 0xffffu; entry[5] = blk.z >> 16;
+   entry[6] = blk.w & 0xffffu; entry[7] = blk.w >> 16;
+}
+// Zeroes the entries between a list's end and the end of its last block (0 is a valid tile index):
+// the bit-exact acceleration loop gathers by every entry of a fetched block before it looks at the
+// count, and what an earlier step left there need not be an index of this step's tile.
+__device__ __forceinline__ void list_pad(char* __restrict__ lists, uint32_t lane_off, int count, int list_cap)
+{
+   if (count >= list_cap + 1) return;
+   uint32_t c = (uint32_t)count;
+   if (c & 1u) { *reinterpret_cast<uint16_t*>(lists + list_entry_off(c, lane_off)) = (uint16_t)0; c += 1u; }
+   if (c & 2u) { *reinterpret_cast<uint32_t*>(lists + list_entry_off(c, lane_off)) = 0u; c += 2u; }
+   if (c & 4u) { *reinterpret_cast<uint2*>(lists + list_entry_off(c, lane_off)) = make_uint2(0u, 0u); }
+}
 // first list word of a particle that has no list (more neighbours than list_cap): no valid
 // entry has segment id 15
 #define NLIST_NO_LIST 0xffffffffu
@@ -158,7 +215,7 @@ __device__ __forceinline__ f32x4 lds_read4(const float* base, int i)
    return *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + i, 16));
 }
 
-static_assert(DENSITY_UNROLL % 2 == 0 && ACCEL_UNROLL % 2 == 0 && NLIST_CAP % 2 == 0 && NLIST_CAP_MAX % 2 == 0, "entries travel in pairs");
+static_assert(DENSITY_UNROLL == LIST_BLOCK_ENTRIES && ACCEL_UNROLL == LIST_BLOCK_ENTRIES, "a trip of the list-driven loops is one block of the lists");
 static_assert(TILE_CAP_MAX + TILE_PAD <= (1 << ListEntry<false>::TBITS) &&
                  TILE_CAP_MAX_WIDE + TILE_PAD <= (1 << ListEntry<true>::TBITS),
               "tile index must fit the list entry");
@@ -506,13 +563,12 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const float h2_screen = k.h2_screen;
    TRIP(TripCounters trips; trips.wave(TRIP_D_WAVES, true); trips.lane(TRIP_D_LANES_L, live ? 1u : 0u);)
    int count = 0;
-   // The list is a column of 16-bit entries: entry j of this lane is the (j & 1) half of word
-   // (j >> 1) * TILE_THREADS + tid.  TEST stores every accepted neighbour with one 2-byte store
-   // (no pairing of entries in registers: the append loop runs to the largest popcount among the
-   // wave's lanes for every chunk, so what counts is instructions per trip).  half = index of the
-   // next entry in units of 16 bits from the lane's first one; step alternates 1 / 2 * TILE_THREADS - 1.
-   uint16_t* const my_entries = reinterpret_cast<uint16_t*>(list_block + tid);
-   uint32_t half = 0, step = 1;
+   // TEST stores every accepted neighbour with one 2-byte store (no pairing of entries in registers:
+   // the append loop runs to the largest popcount among the wave's lanes for every chunk, so what
+   // counts is instructions per trip); pos = where this lane's next entry goes (list_pos_of).
+   char* const lists = reinterpret_cast<char*>(list_block);
+   const uint32_t lane_off = 16u * (uint32_t)tid;
+   uint32_t pos = list_pos_of(0u);
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = sd.D[kk];
@@ -567,23 +623,20 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                   const uint32_t bit = (uint32_t)__builtin_ctz(mask);
                   mask &= mask - 1u;
 #if defined(SPH_ABLATE) && SPH_ABLATE == 10
-                  count ^= (int)(ebase + bit) & (int)half & 1;   // timing only: no store
+                  count ^= (int)(ebase + bit) & (int)pos & 2;   // timing only: no store
 #elif defined(SPH_ABLATE) && SPH_ABLATE == 11
-                  my_entries[0] = (uint16_t)(ebase + bit);        // timing only: every store to the lane's first word
+                  *reinterpret_cast<uint16_t*>(lists + lane_off) = (uint16_t)(ebase + bit);   // timing only: every store to the lane's first entry
 #else
-                  my_entries[half] = (uint16_t)(ebase + bit);
+                  *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
 #endif
-                  half += step;
-                  step = 2 * TILE_THREADS - step;
+                  pos = list_pos_next(pos);
                }
             }
          }
       }
    }
-   // An odd count leaves the second half of the last word unwritten: zero it (a valid tile index).
-   // The acceleration pass gathers by every entry of the words it fetches before it looks at the
-   // count, and what an earlier step left there need not be an index of this step's tile.
-   if ((count & 1) && count < list_cap) my_entries[half] = (uint16_t)0;
+   // (the rest of the list's last block: zeros)
+   list_pad(lists, lane_off, count, list_cap);
    // A particle with more neighbours than its list holds (a scene many times denser than the
    // benchmark's) goes without a list: its lane walks its candidate ranges in the tile one by one
    // here - canonical order, small code - and again in the acceleration pass, which recognises it
@@ -591,7 +644,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const bool overflowed = count > list_cap;
    if (overflowed) {
       list_overflow = 1;
-      list_block[tid] = NLIST_NO_LIST;
+      *reinterpret_cast<uint32_t*>(lists + lane_off) = NLIST_NO_LIST;
    }
    if (__any(overflowed)) {
       // reported to the host (through the acceleration pass), which then enlarges the lists
@@ -637,8 +690,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    // fails it out of the sum and moves the entries behind it up, so that lists and counts are exactly
    // the reference's (the write position never passes the read position, and a trip's words are in
    // registers before its first store).
-   const uint32_t* sum_list = list_block + tid;
    const int listed = overflowed ? 0 : count;   // entries to sum from the list
+   const int lastb = listed > 0 ? (listed - 1) >> 3 : 0;
    int kept = 0;
    TRIP(trips.lane(TRIP_D_LISTED_L, (unsigned)listed);)
    for (int j0 = 0; __any(j0 < listed); j0 += DENSITY_UNROLL) {
@@ -646,14 +699,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
            for (int u = 0; u < DENSITY_UNROLL; u++) trips.wave(TRIP_D_SUMSLOTS_W, __any(j0 + u < listed));)
 #if !(defined(SPH_ABLATE) && (SPH_ABLATE == 1 || SPH_ABLATE == 15))
       uint32_t entry[DENSITY_UNROLL];
-      const int lastw = listed > 0 ? (listed - 1) >> 1 : 0;
-#pragma unroll
-      for (int u = 0; u < DENSITY_UNROLL; u += 2) {
-         const int w = ((j0 + u) >> 1) < lastw ? ((j0 + u) >> 1) : lastw;
-         const uint32_t word = sum_list[w * TILE_THREADS];  // independent loads, all in flight
-         entry[u] = word & 0xffffu;
-         entry[u + 1] = word >> 16;
-      }
+      // (the trip's eight entries: one 16-byte load; a lane past its last block takes that one again)
+      list_block_entries(list_block_load(lists, min(j0 >> 3, lastb), lane_off), entry);
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u++) {
          if (j0 + u < listed) {
@@ -668,7 +715,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                   if (!UNIT_SCALE) d *= k.sim_scale;
                   density_accumulate<UNIT_SCALE>(k, mj, d, density);
                }
-               if (kept != j0 + u) my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry[u];
+               if (kept != j0 + u) *reinterpret_cast<uint16_t*>(lists + list_entry_off((uint32_t)kept, lane_off)) = (uint16_t)entry[u];
                kept++;
             }
          }
@@ -678,8 +725,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 #endif
    }
    if (!overflowed && kept != count) {
-      if (kept & 1) my_entries[(kept >> 1) * (2 * TILE_THREADS) + 1] = (uint16_t)0;
       count = kept;
+      list_pad(lists, lane_off, count, list_cap);
    }
    TRIP(trips.flush(0, 1u << TRIP_D_TEST8_L | 1u << TRIP_D_SLOTS_L | 1u << TRIP_D_POPS_L | 1u << TRIP_D_LISTED_L |
                        1u << TRIP_D_LANES_L);)
@@ -763,9 +810,9 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
       const int c_last = (int)cell_of(g, pb.x, pb.y, pb.z, cxb, cyb, czb);
       const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
       uint32_t* list_block = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS);
-      uint16_t* const my_entries = reinterpret_cast<uint16_t*>(list_block + tid);
-      const uint32_t* sum_list = list_block + tid;
-      uint32_t half = 0, step = 1;
+      char* const lists = reinterpret_cast<char*>(list_block);
+      const uint32_t lane_off = 16u * (uint32_t)tid;
+      uint32_t pos = list_pos_of(0u);   // the append position (list_pos_of(entries this lane's list holds))
       int count = 0;
       float density = 0.0f;
 #pragma unroll 1
@@ -788,11 +835,21 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
          for (int c0 = G; c0 < G + len; c0 += tile_cap) {
             const int have = min(tile_cap, G + len - c0);
             __syncthreads();                 // the previous chunk's readers are done
-            for (int i = tid; i < have; i += TILE_THREADS) {
-               const float4 q = posm[c0 + i];
-               L.x[i] = q.x;
-               L.y[i] = q.y;
-               L.z[i] = q.z;
+            // (TILE_BATCH loads in flight before the first LDS store, as tile_load does: one load
+            // waited for per trip made a chunk of 4 400 entries seventeen round trips long)
+            for (int base = 0; base < have; base += TILE_BATCH * TILE_THREADS) {
+               float4 buf[TILE_BATCH];
+#pragma unroll
+               for (int rr = 0; rr < TILE_BATCH; rr++) buf[rr] = posm[c0 + min(base + tid + rr * TILE_THREADS, have - 1)];
+#pragma unroll
+               for (int rr = 0; rr < TILE_BATCH; rr++) {
+                  const int i = base + tid + rr * TILE_THREADS;
+                  if (i < have) {
+                     L.x[i] = buf[rr].x;
+                     L.y[i] = buf[rr].y;
+                     L.z[i] = buf[rr].z;
+                  }
+               }
             }
             __syncthreads();
             // this lane's candidates inside the chunk, as chunk-local slots
@@ -825,9 +882,8 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                   if (mask != 0u) {
                      const uint32_t bit = (uint32_t)__builtin_ctz(mask);
                      mask &= mask - 1u;
-                     my_entries[half] = (uint16_t)(ebase + bit);
-                     half += step;
-                     step = 2 * TILE_THREADS - step;
+                     *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
+                     pos = list_pos_next(pos);
                   }
                }
             }
@@ -846,8 +902,7 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
 #pragma unroll
                   for (int u = 0; u < CU; u++) {
                      const int j = min(j0 + u, listed > first_new ? listed - 1 : first_new);
-                     const uint32_t word = sum_list[(j >> 1) * TILE_THREADS];
-                     entry[u] = (j & 1) ? word >> 16 : word & 0xffffu;
+                     entry[u] = list_entry_load(lists, (uint32_t)j, lane_off);
                   }
 #pragma unroll
                   for (int u = 0; u < CU; u++) {
@@ -862,7 +917,7 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                            if (!UNIT_SCALE) d *= k.sim_scale;
                            density_accumulate<UNIT_SCALE>(k, mj, d, density);
                            if (kept != j0 + u)
-                              my_entries[(kept >> 1) * (2 * TILE_THREADS) + (kept & 1)] = (uint16_t)entry[u];
+                              *reinterpret_cast<uint16_t*>(lists + list_entry_off((uint32_t)kept, lane_off)) = (uint16_t)entry[u];
                            kept++;
                         }
                      }
@@ -870,17 +925,16 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                }
                if (count <= list_cap && kept != count) {     // the append position follows the list's end
                   count = kept;
-                  half = (uint32_t)((count >> 1) * (2 * TILE_THREADS) + (count & 1));
-                  step = (count & 1) ? 2 * TILE_THREADS - 1 : 1;
+                  pos = list_pos_of((uint32_t)count);
                }
             }
          }
       }
-      if ((count & 1) && count < list_cap) my_entries[half] = (uint16_t)0;
+      list_pad(lists, lane_off, count, list_cap);
       const bool overflowed = count > list_cap;
       if (overflowed) {
          list_overflow = 1;
-         list_block[tid] = NLIST_NO_LIST;
+         *reinterpret_cast<uint32_t*>(lists + lane_off) = NLIST_NO_LIST;
       }
       if (__any(overflowed)) {
          const int without = __popcll(__ballot(overflowed));
@@ -1055,7 +1109,7 @@ __device__ __forceinline__ void fused_integrate(const FusedStep& fs, const PairC
 // workgroup's tile descriptor (in LDS: the entries' segment -> sorted position shift).
 template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
 __device__ __forceinline__ float4
-accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const TileDesc& d,
+accel_from_lists(int p, int cnt, const char* __restrict__ lists, uint32_t lane_off, const TileDesc& d,
                  const float4* __restrict__ posm, const float4* __restrict__ velB,
                  const float* __restrict__ rho, const float* __restrict__ auxc, const PairConsts& k)
 {
@@ -1075,8 +1129,7 @@ accel_from_lists(int p, int cnt, const uint32_t* __restrict__ my_list, const Til
 #pragma unroll
       for (int u = 0; u < U; u++) {
          const int j = min(j0 + u, cnt - 1);
-         const uint32_t word = my_list[(j >> 1) * TILE_THREADS];
-         const uint32_t e = (j & 1) ? word >> 16 : word & 0xffffu;
+         const uint32_t e = list_entry_load(lists, (uint32_t)j, lane_off);
          const int q = ListEntry<WIDE>::tile(e) - ListEntry<WIDE>::shift(d, e);
          pj[u] = posm[q];
          cj[u] = auxc[q];
@@ -1161,12 +1214,14 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          tile_desc_load(desc, gwg, L.desc);
          if (mine) {
             const int gcnt = ncount[gp];
-            const uint32_t* glist = nlist + (size_t)gwg * (size_t)(list_rows(list_cap) * TILE_THREADS) + tid;
-            if (glists == 2u && gcnt > 0 && glist[0] == NLIST_NO_LIST)
+            const char* glists_base = reinterpret_cast<const char*>(
+               nlist + (size_t)gwg * (size_t)(list_rows(list_cap) * TILE_THREADS));
+            const uint32_t goff = 16u * (uint32_t)tid;
+            if (glists == 2u && gcnt > 0 && *reinterpret_cast<const uint32_t*>(glists_base + goff) == NLIST_NO_LIST)
                accel_untiled<UNIT_SCALE, FAST>(gp, posm, velB, rho, auxc, cell_start, g, k, acc, ncount);
             else
-               acc[gp] = accel_from_lists<UNIT_SCALE, UNIFORM_MASS, WIDE, FAST>(gp, gcnt, glist, L.desc, posm, velB,
-                                                                                rho, auxc, k);
+               acc[gp] = accel_from_lists<UNIT_SCALE, UNIFORM_MASS, WIDE, FAST>(gp, gcnt, glists_base, goff, L.desc, posm,
+                                                                                velB, rho, auxc, k);
          }
          __syncthreads();   // L.desc is loaded again below, for this workgroup's own tile
       } else if (mine) {
@@ -1246,11 +1301,10 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 
    // the lane's first list words travel with the tile (requested before the count is known: what
    // a lane with fewer entries reads in the rows of its block is never used)
-   const uint32_t* my_list = nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS) + col;
-   uint32_t entry[ACCEL_UNROLL], next_word[ACCEL_UNROLL / 2];
-   const int last_row = list_rows(list_cap) - 1;
-#pragma unroll
-   for (int u = 0; u < ACCEL_UNROLL / 2; u++) next_word[u] = my_list[(u < last_row ? u : last_row) * TILE_THREADS];
+   const char* lists = reinterpret_cast<const char*>(nlist + (size_t)wg * (size_t)(list_rows(list_cap) * TILE_THREADS));
+   const uint32_t lane_off = 16u * (uint32_t)col;
+   uint32_t entry[ACCEL_UNROLL];
+   uint4 next_blk = list_block_load(lists, 0, lane_off);      // (block 0 of every lane exists)
 
    // the tile: first batch from the registers, then whatever is left
 #pragma unroll
@@ -1286,7 +1340,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    // a particle without a list (marker in its first word; only in workgroups flagged 2): its lane
    // skips the list loop and walks its candidate ranges in the tile afterwards
    bool no_list = false;
-   if (gave_up == 2u && cnt > 0) no_list = my_list[0] == NLIST_NO_LIST;
+   if (gave_up == 2u && cnt > 0) no_list = next_blk.x == NLIST_NO_LIST;
    // FAST: only the last visc_keep() neighbours take part in the viscous sum - and only they are
    // gathered ({v, C}; what every pair needs, m B, is in the tile)
    int first_v = 0;
@@ -1298,11 +1352,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #if defined(SPH_ABLATE) && (SPH_ABLATE == 21 || SPH_ABLATE == 23)
    cnt = 0;   // timing only: prologue and epilogue
 #endif
-   const int lastw = cnt > 0 ? (cnt - 1) >> 1 : 0;
-   // (the words requested before the count was known: a lane past its last word takes that one
-   // again - the exact loop gathers by every entry it holds, used or not)
-#pragma unroll
-   for (int u = 1; u < ACCEL_UNROLL / 2; u++) next_word[u] = u <= lastw ? next_word[u] : next_word[u - 1];
+   // (a lane past its last block takes that one again; the entries between a list's end and the end
+   // of its last block are zeros - list_pad - because the exact loop gathers by every entry it holds)
+   const int lastb = cnt > 0 ? (cnt - 1) >> 3 : 0;
    if constexpr (FAST) {
       const int self_tile = live ? p + L.desc.D[4] : 0;   // (the lane's own entry of the tile)
       // The pressure sum over the whole list: everything it needs of a neighbour is in the tile
@@ -1320,14 +1372,8 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
            trips.lane(TRIP_A_LANES_L - 16, live ? 1u : 0u); trips.lane(TRIP_A_NV_L - 16, (unsigned)(cnt - first_v));)
       for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
          TRIP(trips.wave(TRIP_A_PTRIPS_W - 16, true);)
-#pragma unroll
-         for (int u = 0; u < ACCEL_UNROLL; u++)
-            entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
-#pragma unroll
-         for (int u = 0; u < ACCEL_UNROLL / 2; u++) {
-            const int w = (j0 + ACCEL_UNROLL) / 2 + u;
-            next_word[u] = my_list[(w < lastw ? w : lastw) * TILE_THREADS];
-         }
+         list_block_entries(next_blk, entry);
+         next_blk = list_block_load(lists, min((j0 >> 3) + 1, lastb), lane_off);
          // (the trip's roots taken together - sqrt_rn_batch - and no branch on j0 + u < cnt: a lane
          // past its count takes ITSELF as the neighbour with m B = 0 - r = 0 and a factor of zero:
          // the sum does not move - so that the eight pairs of a trip are one basic block)
@@ -1370,8 +1416,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #pragma unroll
          for (int u = 0; u < VISC_UNROLL; u++) {
             const int j = min(first_v + m0 + u, cnt > 0 ? cnt - 1 : 0);
-            const uint32_t word = my_list[(j >> 1) * TILE_THREADS];
-            const uint32_t e = (j & 1) ? word >> 16 : word & 0xffffu;
+            const uint32_t e = list_entry_load(lists, (uint32_t)j, lane_off);
             tj[u] = ListEntry<WIDE>::tile(e);
             vj[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + u < nv) vj[u] = velB[tj[u] - ListEntry<WIDE>::shift(L.desc, e)];
@@ -1395,9 +1440,9 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    for (int j0 = 0; __any(j0 < cnt); j0 += ACCEL_UNROLL) {
       float4 vj[ACCEL_UNROLL];
       float mj[ACCEL_UNROLL];
+      list_block_entries(next_blk, entry);
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
-         entry[u] = (u & 1) ? next_word[u / 2] >> 16 : next_word[u / 2] & 0xffffu;
          mj[u] = pi.w;
          const int q = ListEntry<WIDE>::tile(entry[u]) - ListEntry<WIDE>::shift(L.desc, entry[u]);
          const int qq = cnt > 0 ? q : p0;  // lanes without neighbours hold no valid entry
@@ -1409,11 +1454,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          if (!UNIFORM_MASS) mj[u] = posm[qq].w;
       }
       // the next trip's list entries travel while this trip's pairs are computed
-#pragma unroll
-      for (int u = 0; u < ACCEL_UNROLL / 2; u++) {
-         const int w = (j0 + ACCEL_UNROLL) / 2 + u;
-         next_word[u] = my_list[(w < lastw ? w : lastw) * TILE_THREADS];
-      }
+      next_blk = list_block_load(lists, min((j0 >> 3) + 1, lastb), lane_off);
 #pragma unroll
       for (int u = 0; u < ACCEL_UNROLL; u++) {
          if (j0 + u < cnt) {

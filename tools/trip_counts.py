@@ -30,12 +30,21 @@ NAMES = {0: "density waves", 1: "TEST chunks (32 slots) per wave", 2: "test8 ste
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4 * 1024 * 1024
+    # second argument: step of the BREAKING dam (gravity + walls) to take the counts at, e.g. 400 =
+    # the compressed transient; default: the column at rest (the bench's headline scene)
+    dense_step = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = S.load_library()
     lib.sph_hip_diag_trips.restype = C.c_int
     p, pos, vel, mass = scenes.dam_break(n)
+    if dense_step:
+        p.apply_gravity = 1
+        p.apply_walls = 1
+        p.gravity[0], p.gravity[1], p.gravity[2] = 0.0, -9.81, 0.0
     out = (C.c_ulonglong * 32)()
     with S.SPH(n, p, mode=S.MODE_FULL_FAST) as sph:
         sph.setParticles(pos, vel, mass)
+        if dense_step:
+            sph.run(dense_step)
         sph.step()
         sph.synchronize()
         lib.sph_hip_diag_trips(out, 32, 1)          # the upload's own sort + first step: discard
@@ -43,11 +52,12 @@ def main():
         sph.synchronize()
         assert lib.sph_hip_diag_trips(out, 32, 1) == 0
         nb = float(sph.getParticles().mNeighborCount.mean())
+        tiles = sph.tileStats()
     v = list(out)
     res = {NAMES[i]: v[i] for i in NAMES}
     dw, lanes = v[0], v[11]
     per = {
-        "particles": n, "neighbours_mean": nb,
+        "particles": n, "neighbours_mean": nb, "breaking_dam_step": dense_step, "tiles": tiles,
         "density: test8 steps issued per wave": v[2] / dw,
         "density: slots tested per particle as issued (8 x test8 per wave)": 8.0 * v[2] / dw,
         "density: slots tested per particle as needed (8 x test8 per lane)": 8.0 * v[3] / lanes,
