@@ -484,8 +484,10 @@ __device__ __forceinline__ uint32_t test8(const TileLds& L, int t, f32x2 px, f32
 // column of the workgroup's list block in global memory; SUM then walks that list once.  The
 // list doubles as the input of the acceleration pass.  A workgroup in which some particle has
 // more than NLIST_CAP neighbours gives up (flag) and runs the untiled code inline instead.
+// (launch bounds: the wide-entry instantiations run at four workgroups per CU at most - LDS - and may
+// take the registers that leaves them: 128)
 template <bool UNIT_SCALE, bool UNIFORM_MASS, bool WIDE, bool FAST>
-__global__ void __launch_bounds__(TILE_THREADS, DENSITY_BLOCKS)
+__global__ void __launch_bounds__(TILE_THREADS, WIDE ? (DENSITY_BLOCKS < 4 ? DENSITY_BLOCKS : 4) : DENSITY_BLOCKS)
 k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__ velp,
                      const uint32_t* __restrict__ cell_start, const int32_t* __restrict__ meta,
                      CellGrid g, PairConsts k, float* __restrict__ rho_out,
@@ -694,13 +696,51 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    const int lastb = listed > 0 ? (listed - 1) >> 3 : 0;
    int kept = 0;
    TRIP(trips.lane(TRIP_D_LISTED_L, (unsigned)listed);)
+   // (the next trip's block travels while this trip's entries are summed; the compaction below only
+   // ever writes behind the current trip's read position, never into the block already fetched)
+   uint4 sum_blk = list_block_load(lists, 0, lane_off);
    for (int j0 = 0; __any(j0 < listed); j0 += DENSITY_UNROLL) {
       TRIP(trips.wave(TRIP_D_SUMTRIPS_W, true);
            for (int u = 0; u < DENSITY_UNROLL; u++) trips.wave(TRIP_D_SUMSLOTS_W, __any(j0 + u < listed));)
 #if !(defined(SPH_ABLATE) && (SPH_ABLATE == 1 || SPH_ABLATE == 15))
       uint32_t entry[DENSITY_UNROLL];
       // (the trip's eight entries: one 16-byte load; a lane past its last block takes that one again)
-      list_block_entries(list_block_load(lists, min(j0 >> 3, lastb), lane_off), entry);
+      list_block_entries(sum_blk, entry);
+      sum_blk = list_block_load(lists, min((j0 >> 3) + 1, lastb), lane_off);
+      if constexpr (WIDE) {
+         // Scenes several times denser than the benchmark's (wide entries = tiles beyond 4064
+         // positions = at most four workgroups per CU): few waves share a SIMD, so the latency of a
+         // neighbour's chain - three LDS reads, the distance, the root, the term - is hidden by the
+         // trip's other neighbours or not at all.  The eight entries as ONE basic block: all reads
+         // first, the roots together, the terms added in list order (a neighbour past the count or
+         // failing the reference's test adds +0.0f); the registers are there at this occupancy.
+         float d2[DENSITY_UNROLL], mj[DENSITY_UNROLL];
+         bool ok[DENSITY_UNROLL];
+#pragma unroll
+         for (int u = 0; u < DENSITY_UNROLL; u++) {
+            const bool valid = j0 + u < listed;
+            const int t = valid ? ListEntry<WIDE>::tile(entry[u]) : 0;
+            mj[u] = pi.w;
+            if (!UNIFORM_MASS) mj[u] = posm[valid ? t - ListEntry<WIDE>::shift(sd, entry[u]) : p0].w;
+            float dx, dy, dz;
+            d2[u] = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+            ok[u] = valid && d2[u] < k.h2;      // the reference's own test, on the reference's own value
+         }
+         float dd[DENSITY_UNROLL];
+#pragma unroll
+         for (int u = 0; u < DENSITY_UNROLL; u++) dd[u] = ok[u] ? d2[u] : 0.0f;
+         sqrt_rn_batch(dd);
+#pragma unroll
+         for (int u = 0; u < DENSITY_UNROLL; u++) {
+            float d = dd[u];
+            if (!UNIT_SCALE) d *= k.sim_scale;
+            const float term = density_term<UNIT_SCALE>(k, mj[u], d);
+            density += ok[u] ? term : 0.0f;
+            if (ok[u] && kept != j0 + u)
+               *reinterpret_cast<uint16_t*>(lists + list_entry_off((uint32_t)kept, lane_off)) = (uint16_t)entry[u];
+            kept += ok[u] ? 1 : 0;
+         }
+      } else {
 #pragma unroll
       for (int u = 0; u < DENSITY_UNROLL; u++) {
          if (j0 + u < listed) {
@@ -719,6 +759,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
                kept++;
             }
          }
+      }
       }
 #else
       kept = listed;

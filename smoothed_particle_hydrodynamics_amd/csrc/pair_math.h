@@ -24,6 +24,19 @@ __device__ __forceinline__ void density_accumulate(const PairConsts& k, float ma
    }
 }
 
+// the same term as a value: m * (k1 * t^3), rounded as density_accumulate rounds it (callers that
+// sum a batch of neighbours add the terms in list order; a neighbour that does not count adds +0.0f,
+// which leaves a density - never negative, never -0 - unchanged bit for bit)
+template <bool INSIDE = false>
+__device__ __forceinline__ float density_term(const PairConsts& k, float mass, float d)
+{
+   float t = (k.hscaled2 - (d * d));
+   t = (t * t * t);
+   const float w = k.kernel1 * t;
+   const float term = (mass * w);
+   return (INSIDE || !(d > k.hscaled)) ? term : 0.0f;
+}
+
 // ---- tolerance mode (SPH_HIP_MODE_FULL_FAST) ----------------------------------------------------
 // The reference ships with -O3 -ffast-math -funsafe-math-optimizations -mfma
 // (reference CMakeLists.txt:21): its own binary is not the IEEE evaluation of src/sph.cpp - the

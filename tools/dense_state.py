@@ -42,3 +42,10 @@ else:
         sph.run(k)
         sph.synchronize()
         print("%d steps: %.3f ms/step" % (k, (time.perf_counter() - t0) / k * 1e3), sph.tileStats(), flush=True)
+        sph.setTiming(S.TIMING_PHASES)
+        for _ in range(4):
+            sph.step()
+        sph.synchronize()
+        t, kk = sph.phaseTotals()
+        print("phases (ms): build %.3f density %.3f acceleration %.3f integrate %.3f" % (
+            t[0] / kk, t[2] / kk, t[4] / kk, t[5] / kk), flush=True)
