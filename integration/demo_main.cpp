@@ -18,8 +18,22 @@ int main(int argc, char** argv)
 {
    const int steps = argc > 1 ? atoi(argv[1]) : 1;
    const char* out = argc > 2 ? argv[2] : "dropin_state.bin";
+   // third argument "phases": drive the protected per-particle members in the reference's own call
+   // pattern (src/sph.cpp:208-289) instead of step() - what a subclass of SPH could do
+   const bool phases = argc > 3 && strcmp(argv[3], "phases") == 0;
    SPH sph;
-   for (int s = 0; s < steps; s++) sph.step();
+   for (int s = 0; s < steps; s++) {
+      if (!phases) {
+         sph.step();
+         continue;
+      }
+      const int n = sph.getParticleCount();
+      sph.voxelizeParticles();
+      for (int i = 0; i < n; i++) sph.findNeighbors(i, nullptr, 0, 0, 0, nullptr);
+      for (int i = 0; i < n; i++) sph.computeDensity(i, nullptr, nullptr);
+      for (int i = 0; i < n; i++) sph.computeAcceleration(i, nullptr, nullptr);
+      for (int i = 0; i < n; i++) sph.integrate(i);
+   }
    // step() returns while the snapshot of its state is still on its way to the host mirror (the
    // GUI reads whatever complete mirror is current); a program that wants the LAST step waits
    printf("dropin: %lld of %d step() calls returned before their snapshot had arrived\n",

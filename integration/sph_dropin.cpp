@@ -217,7 +217,6 @@ void SPH::run()
    int stepCount = 0;
    mkdir("out", 0777);
    std::ofstream energy("out/energy.txt"), timing("out/timing.txt"), momentum("out/angularmomentum.txt");
-   std::ofstream neighbors("out/neighbors.txt");
    momentum << "Step, Angular Momentum" << std::endl;
    energy << "Step, Kinetic Energy, Potential Energy, Total Energy" << std::endl;
    timing << "Step, Voxelize, Find Neighbors, Compute Density, Compute Pressure, "
@@ -231,9 +230,6 @@ void SPH::run()
              << timeComputeDensity << ", " << timeComputePressure << ", " << timeComputeAcceleration
              << ", " << timeIntegrate << std::endl;
       momentum << stepCount << ", " << mAngularMomentumTotal.length() << std::endl;
-      int32_t avg = 0, mx = 0, mn = 0;   // the line step() appends to out/neighbors.txt (:232)
-      check(sph_hip_get_neighbor_stats(g_ctx, &avg, &mx, &mn), "sph_hip_get_neighbor_stats");
-      neighbors << avg << ", " << mx << ", " << mn << std::endl;
       stepCount++;
    }
 }
@@ -252,6 +248,17 @@ void SPH::step()
    if (g_copy_in_flight && sph_hip_download_done(g_ctx, 0) == 1) publish_mirror();
    check(sph_hip_step(g_ctx), "sph_hip_step");
    g_steps_taken++;
+   {
+      // the line the reference's step() appends to out/neighbors.txt (src/sph.cpp:203, 232, 301):
+      // opened in append mode every step, silently dropped when ./out does not exist - in step(), not
+      // in run(), so that a host that drives step() itself (the GUI's single-step button) gets it too
+      std::ofstream neighbors("out/neighbors.txt", std::ios_base::app);
+      if (neighbors) {
+         int32_t avg = 0, mx = 0, mn = 0;
+         check(sph_hip_get_neighbor_stats(g_ctx, &avg, &mx, &mn), "sph_hip_get_neighbor_stats");
+         neighbors << avg << ", " << mx << ", " << mn << std::endl;
+      }
+   }
 
    float ms[6];
    check(sph_hip_get_timings(g_ctx, ms), "sph_hip_get_timings");
@@ -301,14 +308,34 @@ void SPH::initParticlePolitionsSphere()
 }
 void SPH::initParticlePositionsRandom() {}
 
-// ---- per-particle pipeline members: subsumed by sph_hip_step() ---------------------------------
+// ---- per-particle pipeline members (protected; nothing outside step() calls them in the reference).
+// The GPU runs each phase for ALL particles at once, so a subclass that drives the phases itself gets
+// the whole loop from the call for particle 0 and nothing from the others - the same state after
+// "for (i = 0; i < N; i++) phase(i, ...)" as in the reference (src/sph.cpp:216-289), instead of silence.
+// The list arguments are the reference's own members; the lists live on the device
+// (sph_hip_download_neighbor_lists brings them over).
 void SPH::clearGrid() {}
 void SPH::voxelizeParticles() { check(sph_hip_voxelize(g_ctx), "sph_hip_voxelize"); }
-void SPH::findNeighbors(int, uint32_t*, int, int, int, float*) {}
-void SPH::computeDensity(int, uint32_t*, float*) {}
-void SPH::computePressure(int) {}
-void SPH::computeAcceleration(int, uint32_t*, float*) {}
-void SPH::integrate(int) {}
+void SPH::findNeighbors(int particleIndex, uint32_t*, int, int, int, float*)
+{
+   if (particleIndex == 0) check(sph_hip_find_neighbors(g_ctx), "sph_hip_find_neighbors");
+}
+void SPH::computeDensity(int particleIndex, uint32_t*, float*)
+{
+   if (particleIndex == 0) check(sph_hip_compute_density(g_ctx), "sph_hip_compute_density");
+}
+void SPH::computePressure(int) {}      // (a no-op in the reference too: src/sph.cpp:769-775)
+void SPH::computeAcceleration(int particleIndex, uint32_t*, float*)
+{
+   if (particleIndex == 0) check(sph_hip_compute_acceleration(g_ctx), "sph_hip_compute_acceleration");
+}
+void SPH::integrate(int particleIndex)
+{
+   if (particleIndex != 0) return;
+   check(sph_hip_integrate(g_ctx), "sph_hip_integrate");
+   g_steps_taken++;      // (the last phase of a step: sph_dropin_sync_mirror() then fetches this state)
+   check(sph_hip_get_energy(g_ctx, &mKineticEnergyTotal, &mPotentialEnergyTotal), "sph_hip_get_energy");
+}
 int SPH::evaluateNeighbor(int, int) { return 0; }
 int SPH::computeVoxelId(int x, int y, int z) { return (z * mGridCellsY + y) * mGridCellsX + x; }
 void SPH::applyBoundary(vec3, float, vec3*, float, vec3, vec3*) {}

@@ -22,7 +22,7 @@ DEMO = os.path.join(ROOT, "integration", "_ref", "sph_dropin_demo")
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
 
 
-def run_demo(tmp_path, steps, full=False, sync=False):
+def run_demo(tmp_path, steps, full=False, sync=False, phases=False):
     if not os.path.exists(DEMO):
         pytest.skip("integration/_ref/sph_dropin_demo not built (needs the reference tree)")
     out = str(tmp_path / "state.bin")
@@ -34,8 +34,8 @@ def run_demo(tmp_path, steps, full=False, sync=False):
     if sync:
         env["SPH_DROPIN_SYNC_MIRROR"] = "1"
     try:
-        res = subprocess.run([DEMO, str(steps), out], capture_output=True, text=True, timeout=300,
-                             env=env)
+        res = subprocess.run([DEMO, str(steps), out] + (["phases"] if phases else []), capture_output=True,
+                             text=True, timeout=300, env=env, cwd=str(tmp_path))
     except OSError as exc:
         pytest.skip("cannot execute the demo binary here: %s" % exc)
     if res.returncode != 0 and "error while loading shared libraries" in res.stderr:
@@ -94,3 +94,25 @@ def test_dropin_full_mode_mirrors_the_voxel_grid_too(hiplib, tmp_path):
         assert np.array_equal(state["rho"], part.mDensity)
         assert np.array_equal(state["acc"], part.mAcceleration)
         assert np.array_equal(state["ncount"], part.mNeighborCount)
+
+
+def test_dropin_protected_phase_members_do_the_work(hiplib, tmp_path):
+    """a subclass that drives the protected per-particle members itself, in the reference's own call
+    pattern (src/sph.cpp:208-289: voxelize, then N x findNeighbors, N x computeDensity, N x
+    computeAcceleration, N x integrate): each phase runs on the GPU for all particles at the call
+    for particle 0 - same goldens as step()"""
+    state, _ = run_demo(tmp_path, 3, phases=True)
+    g = GOLDEN["ref_sphere_M32_steps3"]["sha256"]
+    for k in ("ncount", "rho", "acc", "pos", "vel"):
+        assert sha(state[k]) == g[k], k
+
+
+def test_dropin_step_appends_to_neighbors_txt_when_out_exists(hiplib, tmp_path):
+    """the reference's step() appends "avg, max, min" to out/neighbors.txt every step when ./out
+    exists (src/sph.cpp:203, 232) - also for a host that never calls run()"""
+    os.mkdir(str(tmp_path / "out"))
+    run_demo(tmp_path, 3)
+    lines = open(str(tmp_path / "out" / "neighbors.txt")).read().strip().splitlines()
+    assert len(lines) == 3
+    avg, mx, mn = (int(v) for v in lines[0].split(","))
+    assert avg == 0 and mx >= 4 and mn == 0      # the shipped search finds 0.19 neighbours per particle: integer division

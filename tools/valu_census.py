@@ -72,7 +72,7 @@ def source_spans():
     chunk0 = find(ft, "for (int t0 = (ts < te) ? (ts & ~3) : te;", k0)
     keep0 = find(ft, "// keep only slots inside [ts, te)", k0)
     app0 = find(ft, "// append the set bits, ascending", k0)
-    app1 = find(ft, "// An odd count leaves the second half of the last word unwritten", k0)
+    app1 = find(ft, "// (the rest of the list's last block: zeros)", k0)
     walk0 = find(ft, "if (__any(overflowed) && overflowed) {", k0)
     sum0 = find(ft, "// SUM: one pass over the list, in canonical order", k0)
     sum1 = find(ft, "if (!overflowed && kept != count) {", k0)
