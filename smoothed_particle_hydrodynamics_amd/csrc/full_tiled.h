@@ -161,6 +161,18 @@ __device__ __forceinline__ void list_pad(char* __restrict__ lists, uint32_t lane
    if (c & 2u) { *reinterpret_cast<uint32_t*>(lists + list_entry_off(c, lane_off)) = 0u; c += 2u; }
    if (c & 4u) { *reinterpret_cast<uint2*>(lists + list_entry_off(c, lane_off)) = make_uint2(0u, 0u); }
 }
+// Diagnostic builds with -DSPH_STOREPROBE (tools/dense_state.py probe): a flag the host flips between
+// steps; while it is set the tiled density pass's append keeps one 2-byte store in eight (wrong lists -
+// the step's density pass is timed and the state thrown away): what the append's stores cost.
+#if defined(SPH_STOREPROBE)
+#ifndef SPH_DIAGNOSTIC_BUILD
+#error "SPH_STOREPROBE needs -DSPH_DIAGNOSTIC_BUILD"
+#endif
+__device__ int g_store_probe;
+#define STORE_PROBE_KEEPS(pos) (!store_probe || ((pos) & 14u) == 14u)
+#else
+#define STORE_PROBE_KEEPS(pos) true
+#endif
 // first list word of a particle that has no list (more neighbours than list_cap): no valid
 // entry has segment id 15
 #define NLIST_NO_LIST 0xffffffffu
@@ -571,6 +583,9 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    char* const lists = reinterpret_cast<char*>(list_block);
    const uint32_t lane_off = 16u * (uint32_t)tid;
    uint32_t pos = list_pos_of(0u);
+#if defined(SPH_STOREPROBE)
+   const int store_probe = g_store_probe;
+#endif
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) {
       const int D = sd.D[kk];
@@ -629,7 +644,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 #elif defined(SPH_ABLATE) && SPH_ABLATE == 11
                   *reinterpret_cast<uint16_t*>(lists + lane_off) = (uint16_t)(ebase + bit);   // timing only: every store to the lane's first entry
 #else
-                  *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
+                  if (STORE_PROBE_KEEPS(pos))
+                     *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
 #endif
                   pos = list_pos_next(pos);
                }

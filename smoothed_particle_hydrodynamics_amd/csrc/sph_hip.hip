@@ -915,6 +915,16 @@ extern "C" int sph_hip_diag_trips(unsigned long long* out, int n, int reset)
 }
 #endif
 
+#ifdef SPH_STOREPROBE
+// diagnostic builds with -DSPH_STOREPROBE only (tools/dense_state.py probe): csrc/full_tiled.h, g_store_probe
+extern "C" int sph_hip_diag_store_probe(int on)
+{
+   if (hipDeviceSynchronize() != hipSuccess ||
+       hipMemcpyToSymbol(HIP_SYMBOL(g_store_probe), &on, sizeof(on)) != hipSuccess) return SPH_HIP_ERR_DEVICE;
+   return SPH_HIP_OK;
+}
+#endif
+
 int sph_hip_selftest_sqrt(int device, uint64_t* mismatches, uint32_t* first_bad)
 {
    if (hipSetDevice(device) != hipSuccess) {
