@@ -71,6 +71,32 @@ struct TripCounters {
 #define TRIP(x)
 #endif
 
+// SPH_PHASECLOCK (diagnostic builds only, tools/phase_clock.py): where a workgroup of the two tiled
+// pair kernels spends its life - thread 0 reads the constant-rate clock (100 MHz) at the marks and adds
+// the time since the last mark to g_phase[kernel][workgroup][phase] (marks 0.. = density, 16.. =
+// acceleration; no atomics: a first version with six contended atomicAdd per workgroup took the
+// density pass from 0.55 to 0.92 ms).  What is left of a workgroup's residency (launch duration x workgroups per CU / workgroups
+// of a CU) after the marked phases is the drain of its stores and the dispatch of its successor.
+#ifdef SPH_PHASECLOCK
+#ifndef SPH_DIAGNOSTIC_BUILD
+#error "SPH_PHASECLOCK is for diagnostic builds only: add -DSPH_DIAGNOSTIC_BUILD"
+#endif
+#define PHASE_WGS 65536
+__device__ unsigned int g_phase[2][PHASE_WGS][8];   // [kernel][workgroup][phase]: 10 ns ticks, [7] = 1 when written
+#define PHASE_BEGIN() unsigned long long ph_t = threadIdx.x == 0 ? wall_clock64() : 0ull
+#define PHASE_MARK(i)                                                                               \
+   if (threadIdx.x == 0 && blockIdx.x < PHASE_WGS) {                                                \
+      const unsigned long long ph_now = wall_clock64();                                             \
+      g_phase[(i) >> 4][blockIdx.x][(i) & 7] = (unsigned int)(ph_now - ph_t);                       \
+      ph_t = ph_now;                                                                                \
+   }
+#define PHASE_COUNT(i) if (threadIdx.x == 0 && blockIdx.x < PHASE_WGS) g_phase[(i) >> 4][blockIdx.x][7] = 1u
+#else
+#define PHASE_BEGIN()
+#define PHASE_MARK(i)
+#define PHASE_COUNT(i)
+#endif
+
 // The tile lives in dynamic LDS: its capacity (candidate positions per workgroup) is a launch
 // parameter, chosen by the host from the tile sizes the previous steps needed, because the
 // workgroups a CU can hold (and with them the latency hiding of both passes) is set by the LDS
@@ -161,18 +187,6 @@ __device__ __forceinline__ void list_pad(char* __restrict__ lists, uint32_t lane
    if (c & 2u) { *reinterpret_cast<uint32_t*>(lists + list_entry_off(c, lane_off)) = 0u; c += 2u; }
    if (c & 4u) { *reinterpret_cast<uint2*>(lists + list_entry_off(c, lane_off)) = make_uint2(0u, 0u); }
 }
-// Diagnostic builds with -DSPH_STOREPROBE (tools/dense_state.py probe): a flag the host flips between
-// steps; while it is set the tiled density pass's append keeps one 2-byte store in eight (wrong lists -
-// the step's density pass is timed and the state thrown away): what the append's stores cost.
-#if defined(SPH_STOREPROBE)
-#ifndef SPH_DIAGNOSTIC_BUILD
-#error "SPH_STOREPROBE needs -DSPH_DIAGNOSTIC_BUILD"
-#endif
-__device__ int g_store_probe;
-#define STORE_PROBE_KEEPS(pos) (!store_probe || ((pos) & 14u) == 14u)
-#else
-#define STORE_PROBE_KEEPS(pos) true
-#endif
 // first list word of a particle that has no list (more neighbours than list_cap): no valid
 // entry has segment id 15
 #define NLIST_NO_LIST 0xffffffffu
@@ -184,6 +198,16 @@ static_assert(NLIST_CAP <= NLIST_CAP_MAX, "initial list capacity");
 #endif
 #ifndef APPEND_POPS
 #define APPEND_POPS 4     // accepted candidates appended per trip of the append loop
+#endif
+// The tiled density pass appends through LDS: a lane collects the eight entries of its current list
+// block in a 16-byte slot of its own and writes the block with ONE 16-byte store when it is full (and
+// the last, partial one once at the end).  The texture addresser was busy 80 % of that pass with the
+// 2-byte stores of the append - one per accepted neighbour, each to a 16-byte slot of its own, 13 L2
+// requests per wave-instruction - and every other load of the CU queued behind them: with seven stores in
+// eight left out (a probe, lists wrong) a workgroup's life went from 55 to 45 us, its prologue from 13 to
+// 9 us (tools/phase_clock.py, tools/pmc_latency.sh, profiles/r4_notes.md 4c).
+#ifndef APPEND_STAGED
+#define APPEND_STAGED 1
 #endif
 #ifndef ACCEL_UNROLL
 #define ACCEL_UNROLL 8
@@ -512,6 +536,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 {
    // A slab whose acceleration pass integrates (FusedStep) writes one pair of energy partial sums
    // per workgroup that owns particles; the others' must read zero whatever an earlier step left
+   PHASE_BEGIN();
    if (epart_clear && threadIdx.x < 2) epart_clear[2 * blockIdx.x + threadIdx.x] = 0.0;
    __shared__ TileDesc sd;
    __shared__ int list_overflow;
@@ -558,6 +583,21 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       if (inline_giveups && tid == 0) nlist_overflow[wg] = 1u;
       return;
    }
+#if APPEND_STAGED
+   // The three arrays are packed to the tile's own size; what the launch's capacity leaves free behind
+   // them holds the append's staging slots (16 bytes per lane).  A tile that leaves less than that - one
+   // workgroup in a hundred at the benchmark's density - appends with 2-byte stores as before round 4.
+   char* stage_lane = nullptr;
+   // (workgroup-uniform, and said so: a scalar branch around each pop's store, not an exec mask)
+   const int packed = __builtin_amdgcn_readfirstlane(((sd.total + 31) & ~31) + TILE_PAD);
+   const bool staged = (tile_cap + TILE_PAD - packed) * (int)DENSITY_TILE_BYTES >= 16 * TILE_THREADS;
+   if (staged) {
+      L.y = L.x + packed;
+      L.z = L.y + packed;
+      stage_lane = reinterpret_cast<char*>(L.z + packed) + 16 * tid;
+      *reinterpret_cast<uint4*>(stage_lane) = make_uint4(0u, 0u, 0u, 0u);
+   }
+#endif
    RowRanges r;
 #pragma unroll
    for (int kk = 0; kk < 9; kk++) r.s[kk] = r.e[kk] = 0;
@@ -568,7 +608,9 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       row_ranges(g, cell_start, cx, cy, cz, r);
 #endif
    }
+   PHASE_MARK(0);   // descriptor, own position, row ranges
    tile_load(posm, sd, L);
+   PHASE_MARK(1);   // tile
    const int self_t = p + sd.D[4];
    const f32x2 px = {pi.x, pi.x}, py = {pi.y, pi.y}, pz = {pi.z, pi.z};
    // uniform base of the workgroup's list block; lanes address it with 32-bit offsets
@@ -583,78 +625,102 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    char* const lists = reinterpret_cast<char*>(list_block);
    const uint32_t lane_off = 16u * (uint32_t)tid;
    uint32_t pos = list_pos_of(0u);
-#if defined(SPH_STOREPROBE)
-   const int store_probe = g_store_probe;
-#endif
+   // TEST + append over the nine rows, compiled twice: for a workgroup that stages its appends in LDS
+   // (nearly all) and for one whose tile leaves no room (a branch on that in every pop cost 10 us at 4M)
+   auto test_and_append = [&](auto staged_c) {
+      constexpr bool STAGED = decltype(staged_c)::value;
 #pragma unroll
-   for (int kk = 0; kk < 9; kk++) {
-      const int D = sd.D[kk];
-      const uint32_t kbits = ListEntry<WIDE>::tag(kk);
-      const int ts = (int)r.s[kk] + D;
-      const int te = (int)r.e[kk] + D;
-      // chunks of 32 tile slots starting at a 4-aligned slot; one acceptance bit per slot
-      TRIP(trips.lane(TRIP_D_SLOTS_L, te > ts ? (unsigned)(te - ts) : 0u);)
-      for (int t0 = (ts < te) ? (ts & ~3) : te; __any(t0 < te); t0 += 32) {
-         uint32_t mask = 0;
-         TRIP(trips.wave(TRIP_D_CHUNKS_W, true);
-              for (int q8 = 0; q8 < 4; q8++) {
-                 trips.wave(TRIP_D_TEST8_W, __any(t0 + 8 * q8 < te));
-                 trips.lane(TRIP_D_TEST8_L, t0 + 8 * q8 < te ? 1u : 0u);
-              })
+      for (int kk = 0; kk < 9; kk++) {
+         const int D = sd.D[kk];
+         const uint32_t kbits = ListEntry<WIDE>::tag(kk);
+         const int ts = (int)r.s[kk] + D;
+         const int te = (int)r.e[kk] + D;
+         // chunks of 32 tile slots starting at a 4-aligned slot; one acceptance bit per slot
+         TRIP(trips.lane(TRIP_D_SLOTS_L, te > ts ? (unsigned)(te - ts) : 0u);)
+         for (int t0 = (ts < te) ? (ts & ~3) : te; __any(t0 < te); t0 += 32) {
+            uint32_t mask = 0;
+            TRIP(trips.wave(TRIP_D_CHUNKS_W, true);
+                 for (int q8 = 0; q8 < 4; q8++) {
+                    trips.wave(TRIP_D_TEST8_W, __any(t0 + 8 * q8 < te));
+                    trips.lane(TRIP_D_TEST8_L, t0 + 8 * q8 < te ? 1u : 0u);
+                 })
 #if defined(SPH_ABLATE) && SPH_ABLATE == 2
-         if (false) {
+            if (false) {
 #else
-         if (t0 < te) {
+            if (t0 < te) {
 #endif
-            mask = test8(L, t0, px, py, pz, h2_screen);
-            if (t0 + 8 < te) mask |= test8(L, t0 + 8, px, py, pz, h2_screen) << 8;
-            if (t0 + 16 < te) mask |= test8(L, t0 + 16, px, py, pz, h2_screen) << 16;
-            if (t0 + 24 < te) mask |= test8(L, t0 + 24, px, py, pz, h2_screen) << 24;
-            // keep only slots inside [ts, te), and not the particle itself
-            const int lo = ts - t0, hi = te - t0;
-            if (lo > 0) mask &= ~0u << lo;
-            if (hi < 32) mask &= ~(~0u << hi);
-            if (kk == 4) {
-               const int sb = self_t - t0;
-               if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
+               mask = test8(L, t0, px, py, pz, h2_screen);
+               if (t0 + 8 < te) mask |= test8(L, t0 + 8, px, py, pz, h2_screen) << 8;
+               if (t0 + 16 < te) mask |= test8(L, t0 + 16, px, py, pz, h2_screen) << 16;
+               if (t0 + 24 < te) mask |= test8(L, t0 + 24, px, py, pz, h2_screen) << 24;
+               // keep only slots inside [ts, te), and not the particle itself
+               const int lo = ts - t0, hi = te - t0;
+               if (lo > 0) mask &= ~0u << lo;
+               if (hi < 32) mask &= ~(~0u << hi);
+               if (kk == 4) {
+                  const int sb = self_t - t0;
+                  if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
+               }
+               // a list that would overflow stops growing here (checked per chunk, not per entry):
+               // the particle goes without a list anyway
+               count += __builtin_popcount(mask);
+               if (count > list_cap) {
+                  mask = 0u;
+                  count = list_cap + 1;
+               }
             }
-            // a list that would overflow stops growing here (checked per chunk, not per entry):
-            // the particle goes without a list anyway
-            count += __builtin_popcount(mask);
-            if (count > list_cap) {
-               mask = 0u;
-               count = list_cap + 1;
-            }
-         }
 #if defined(SPH_ABLATE) && (SPH_ABLATE == 9 || SPH_ABLATE == 12 || SPH_ABLATE == 14 || SPH_ABLATE == 15)
-         mask = 0u;   // timing only: no lists (15: and no SUM either - tools/valu_census.py)
+            mask = 0u;   // timing only: no lists (15: and no SUM either - tools/valu_census.py)
 #endif
-         // append the set bits, ascending, to the lane's neighbour list
-         const uint32_t ebase = kbits | (uint32_t)t0;
-         while (__any(mask != 0u)) {
-            TRIP(trips.wave(TRIP_D_POPLOOPS_W, true);)
+            // append the set bits, ascending, to the lane's neighbour list
+            const uint32_t ebase = kbits | (uint32_t)t0;
+            while (__any(mask != 0u)) {
+               TRIP(trips.wave(TRIP_D_POPLOOPS_W, true);)
 #pragma unroll
-            for (int rep = 0; rep < APPEND_POPS; rep++) {   // several pops per trip: less loop control
-               TRIP(trips.wave(TRIP_D_POPS_W, __any(mask != 0u)); trips.lane(TRIP_D_POPS_L, mask != 0u ? 1u : 0u);)
-               if (mask != 0u) {
-                  const uint32_t bit = (uint32_t)__builtin_ctz(mask);
-                  mask &= mask - 1u;
-#if defined(SPH_ABLATE) && SPH_ABLATE == 10
-                  count ^= (int)(ebase + bit) & (int)pos & 2;   // timing only: no store
-#elif defined(SPH_ABLATE) && SPH_ABLATE == 11
-                  *reinterpret_cast<uint16_t*>(lists + lane_off) = (uint16_t)(ebase + bit);   // timing only: every store to the lane's first entry
+               for (int rep = 0; rep < APPEND_POPS; rep++) {   // several pops per trip: less loop control
+                  TRIP(trips.wave(TRIP_D_POPS_W, __any(mask != 0u)); trips.lane(TRIP_D_POPS_L, mask != 0u ? 1u : 0u);)
+                  if (mask != 0u) {
+                     const uint32_t bit = (uint32_t)__builtin_ctz(mask);
+                     mask &= mask - 1u;
+#if APPEND_STAGED
+                     const uint32_t in_block = pos & 14u;   // the entry's two bytes inside its 16-byte block
+                     if constexpr (STAGED) {
+                        *reinterpret_cast<uint16_t*>(stage_lane + in_block) = (uint16_t)(ebase + bit);
+                        if (in_block == 14u)                // the block is complete: one 16-byte store
+                           *reinterpret_cast<uint4*>(lists + list_pos_off(pos & ~14u, lane_off)) =
+                              *reinterpret_cast<const uint4*>(stage_lane);
+                     } else {
+                        *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
+                     }
 #else
-                  if (STORE_PROBE_KEEPS(pos))
                      *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
 #endif
-                  pos = list_pos_next(pos);
+                     pos = list_pos_next(pos);
+                  }
                }
             }
          }
       }
-   }
+   };
+#if APPEND_STAGED
+   if (staged) test_and_append(std::true_type());
+   else test_and_append(std::false_type());
+#else
+   test_and_append(std::false_type());
+#endif
+   PHASE_MARK(2);   // TEST + append
+#if APPEND_STAGED
+   // The last block, partly filled (or block 0 of a lane without neighbours): the slot as it is - what
+   // lies behind the list's end are entries of the lane's previous block or the zeros the slot started
+   // with, valid indices of this tile either way, which is all list_pad's zeros are there for.
+   if (!staged)
+      list_pad(lists, lane_off, count, list_cap);
+   else if (count <= list_cap && ((count & 7) != 0 || count == 0))
+      *reinterpret_cast<uint4*>(lists + list_pos_off(pos & ~14u, lane_off)) = *reinterpret_cast<const uint4*>(stage_lane);
+#else
    // (the rest of the list's last block: zeros)
    list_pad(lists, lane_off, count, list_cap);
+#endif
    // A particle with more neighbours than its list holds (a scene many times denser than the
    // benchmark's) goes without a list: its lane walks its candidate ranges in the tile one by one
    // here - canonical order, small code - and again in the acceleration pass, which recognises it
@@ -708,6 +774,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    // fails it out of the sum and moves the entries behind it up, so that lists and counts are exactly
    // the reference's (the write position never passes the read position, and a trip's words are in
    // registers before its first store).
+   PHASE_MARK(3);   // pad, particles without a list
    const int listed = overflowed ? 0 : count;   // entries to sum from the list
    const int lastb = listed > 0 ? (listed - 1) >> 3 : 0;
    int kept = 0;
@@ -787,6 +854,7 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
    }
    TRIP(trips.flush(0, 1u << TRIP_D_TEST8_L | 1u << TRIP_D_SLOTS_L | 1u << TRIP_D_POPS_L | 1u << TRIP_D_LISTED_L |
                        1u << TRIP_D_LANES_L);)
+   PHASE_MARK(4);   // SUM
    if (live) {
       rho_out[p] = density;
       const float2 bc = FAST ? neighbor_terms_fast(k, density, pi.w) : neighbor_terms(k, density, pi.w);
@@ -797,6 +865,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
       auxc_out[p] = FAST ? bc.x : bc.y;
       ncount[p] = count;
    }
+   PHASE_MARK(5);   // results issued
+   PHASE_COUNT(15);
 }
 
 // ---- density pass of the workgroups whose tile fits no capacity: one row segment at a time ----------
@@ -1226,6 +1296,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
                    const uint32_t* __restrict__ giveup, int part, int list_cap,
                    int* __restrict__ tile_feedback, FusedStep fs, int tile_cap_density)
 {
+   PHASE_BEGIN();
    __shared__ AccelLds L;
    float4* xyzc = reinterpret_cast<float4*>(tile_lds_dynamic);
    constexpr int BATCH = TILE_BATCH;
@@ -1299,6 +1370,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
    if (gave_up == 1u) return;
    if (tid < (int)(sizeof(TileDesc) / sizeof(int))) reinterpret_cast<int*>(&L.desc)[tid] = desc_word;
    __syncthreads();
+   PHASE_MARK(16);   // ranges, flags, descriptor
    const int total = L.desc.total;
    // does not fit this pass's wider entries, or did not fit the density pass's capacity (then it
    // may fit this one and have lists all the same - k_full_density_chunked writes them): either way
@@ -1390,6 +1462,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
 #undef total
 #endif
 
+   PHASE_MARK(17);   // tile, own loads, first list block
    AccelState s;
    accel_begin(k, s, pi, vi, rho_i);
    // every listed pair passed the exact d2 < h2 test: the division's range checks are uniform
@@ -1464,6 +1537,7 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
       }
       // The viscous sum over the list's last visc_keep() entries (ascending, as everywhere): the
       // only neighbours whose {v, C} is gathered, with the reference's stored distance.
+      PHASE_MARK(18);   // pressure loop
       const int nv = cnt - first_v;
       TRIP(for (int m0 = 0; __any(m0 < nv); m0 += VISC_UNROLL) trips.wave(TRIP_A_VTRIPS_W - 16, true);
            trips.flush(16, 1u << (TRIP_A_CNT_L - 16) | 1u << (TRIP_A_NV_L - 16) | 1u << (TRIP_A_LANES_L - 16));)
@@ -1566,8 +1640,12 @@ k_full_accel_lists(const float4* __restrict__ posm, const float4* __restrict__ v
          }
       }
    }
+   PHASE_MARK(19);   // viscous loop (exact arithmetic: the one pair loop)
    if (FAST) accel_fast_finish(k, s);
    const float4 a_i = accel_end<UNIT_SCALE>(k, s);
    if (live) acc[p] = a_i;
+   PHASE_MARK(20);   // the sum's end, acceleration issued
    if (fs.on) fused_integrate<UNIT_SCALE>(fs, k, g, p, live, pi, a_i, wg);
+   PHASE_MARK(21);   // integrate, hash, count, energy sums
+   PHASE_COUNT(31);
 }

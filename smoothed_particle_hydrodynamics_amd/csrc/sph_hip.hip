@@ -915,12 +915,24 @@ extern "C" int sph_hip_diag_trips(unsigned long long* out, int n, int reset)
 }
 #endif
 
-#ifdef SPH_STOREPROBE
-// diagnostic builds with -DSPH_STOREPROBE only (tools/dense_state.py probe): csrc/full_tiled.h, g_store_probe
-extern "C" int sph_hip_diag_store_probe(int on)
+#ifdef SPH_PHASECLOCK
+// diagnostic builds with -DSPH_PHASECLOCK only (tools/phase_clock.py): csrc/full_tiled.h, g_phase
+extern "C" int sph_hip_diag_phases(unsigned long long* out, int n, int reset)
 {
+   // out[0..7] / out[16..23]: sums over the workgroups that wrote (density / acceleration), [7] / [23] their number
+   static unsigned int h[2][PHASE_WGS][8];
    if (hipDeviceSynchronize() != hipSuccess ||
-       hipMemcpyToSymbol(HIP_SYMBOL(g_store_probe), &on, sizeof(on)) != hipSuccess) return SPH_HIP_ERR_DEVICE;
+       hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return SPH_HIP_ERR_DEVICE;
+   for (int i = 0; i < n && i < 32; i++) out[i] = 0;
+   for (int kq = 0; kq < 2; kq++)
+      for (int w = 0; w < PHASE_WGS; w++)
+         if (h[kq][w][7])
+            for (int i = 0; i < 8; i++)
+               if (16 * kq + i < n) out[16 * kq + i] += h[kq][w][i];
+   if (reset) {
+      memset(h, 0, sizeof(h));
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h)) != hipSuccess) return SPH_HIP_ERR_DEVICE;
+   }
    return SPH_HIP_OK;
 }
 #endif

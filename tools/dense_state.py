@@ -7,9 +7,7 @@ with a counter read each and does not finish in a gpurun call: r4 notes, call 11
 
 `save STEP FILE` steps the 4M-particle dam (gravity + walls, tolerance-mode arithmetic) to STEP and
 writes positions and velocities; `run FILE K` uploads them, grows the lists as the scene needs
-(4 untimed steps), and takes K more steps.  `probe FILE` (a -DSPH_STOREPROBE diagnostic build, loaded with
-SPH_HIP_ALLOW_DIAGNOSTIC=1): the density phase of two ordinary steps, then of one step whose append keeps one
-store in eight (sph_hip_diag_store_probe) - what the append's 2-byte stores cost in that scene."""
+(4 untimed steps), and takes K more steps."""
 import os
 import sys
 import time
@@ -51,20 +49,3 @@ else:
         t, kk = sph.phaseTotals()
         print("phases (ms): build %.3f density %.3f acceleration %.3f integrate %.3f" % (
             t[0] / kk, t[2] / kk, t[4] / kk, t[5] / kk), flush=True)
-        if sys.argv[1] == "probe":
-            import ctypes as C
-            from smoothed_particle_hydrodynamics_amd import lib as L
-            hip = L.load_library()
-            hip.sph_hip_diag_store_probe.restype = C.c_int
-
-            def one(label):
-                t0, k0 = sph.phaseTotals()
-                sph.step()
-                sph.synchronize()
-                t1, k1 = sph.phaseTotals()
-                print("%s: density %.3f ms, acceleration %.3f ms" % (label, t1[2] - t0[2], t1[4] - t0[4]), flush=True)
-            one("ordinary step")
-            one("ordinary step")
-            assert hip.sph_hip_diag_store_probe(1) == 0
-            one("one store in eight")
-            assert hip.sph_hip_diag_store_probe(0) == 0
