@@ -390,7 +390,12 @@ def valu_issue(prof, pair_ms, arithmetic="fast"):
     clock = (prof or {}).get("shader_clock_ghz_while_profiled") or census["ghz"]
     cycles = census["pair"]["issue_cycles_per_simd"]
     have = pair_ms * 1e-3 * clock * 1e9
-    return {"frac": cycles / have,
+    return {"frac": min(1.0, cycles / have),
+            "frac_additive_prices": cycles / have,
+            "prices": "per opcode, measured in isolation and summed; mixed streams (tools/ubench/valu6.hip, "
+                      "profiles/r4_valu_mix.txt) deviate from the sum by several per cent both ways - fp32 operations "
+                      "hide behind wide-class ones, packed and plain integer ones cost more next to them - so a sum "
+                      "above 1 is clamped: the pass cannot use more than all of its issue cycles",
             "issue_cycles_per_simd_per_launch_pair": cycles,
             "simd_cycles_per_launch_pair": have, "clock_ghz": clock, "simds": 1024,
             "wave_instructions_per_launch_pair": census["pair"]["wave_instructions_per_launch_pair"],

@@ -11,7 +11,9 @@ Three measured inputs, no model of the code:
      .loc directives), every VALU instruction attributed to the phase whose source lines it came from
      (helpers inlined from sph_device.h / pair_math.h inherit the phase of the code around them;
      code that the 4M column never runs - untiled give-up bodies, the walk of a particle without a
-     list, sqrtf's slow path - is left out of the mix).
+     list, sqrtf's slow path - is left out of the mix; TEST + append are compiled twice, for workgroups
+     that stage their appends in LDS and for the one in a hundred that cannot: both copies share
+     their source lines, so the mix of those two phases is the average of the two).
   3. PRICES per opcode: tools/ubench/valu3.hip + valu5.hip, cycles per wave-instruction per SIMD
      with every SIMD saturated (profiles/r3_valu_prices.json, r4_valu_prices_more.json).
 cycles(phase) = dynamic count x sum over opcodes of (share of the phase's static mix x price).
@@ -72,7 +74,7 @@ def source_spans():
     chunk0 = find(ft, "for (int t0 = (ts < te) ? (ts & ~3) : te;", k0)
     keep0 = find(ft, "// keep only slots inside [ts, te)", k0)
     app0 = find(ft, "// append the set bits, ascending", k0)
-    app1 = find(ft, "// (the rest of the list's last block: zeros)", k0)
+    app1 = find(ft, "if (staged) test_and_append(std::true_type());", k0)
     walk0 = find(ft, "if (__any(overflowed) && overflowed) {", k0)
     sum0 = find(ft, "// SUM: one pass over the list, in canonical order", k0)
     sum1 = find(ft, "if (!overflowed && kept != count) {", k0)
@@ -229,7 +231,10 @@ def main():
     valu = lambda t, v: t[v]["SQ_INSTS_VALU"]
     # dynamic wave-instructions per wave, by phase (differences of builds)
     test8 = trips["density: test8 steps issued per wave"]
-    static_test8 = sum(hd["d_test"].values()) / 36.0                   # 9 rows x 4 steps, all alike
+    # 9 rows x 4 steps, all alike - in each of the two copies of TEST + append (staged / direct appends)
+    copies = 2 if "test_and_append(std::false_type())" in open(os.path.join(CSRC, "full_tiled.h")).read() else 1
+    # (the screen_pair / test8 helpers above the kernel are inlined into both copies and attributed once per copy)
+    static_test8 = sum(hd["d_test"].values()) / (36.0 * copies)
     test_chunk = valu(D, "abl15") - valu(D, "abl2")
     d_test = min(test8 * static_test8, test_chunk)
     dyn = collections.OrderedDict([
@@ -279,18 +284,24 @@ def main():
     for key, name, us in (("d", "k_full_density_tiled", a.density_us), ("a", "k_full_accel_lists", a.accel_us)):
         n, cyc, nonarith = tot[key]
         have = us * 1e-6 * a.ghz * 1e9
-        frac = waves_per_simd * cyc / have
+        raw = waves_per_simd * cyc / have
+        frac = min(1.0, raw)
         pair_cycles += waves_per_simd * cyc
         measured = valu(D if key == "d" else A, "base")
         print("**%s**: %.0f VALU wave-instructions per wave (SQ_INSTS_VALU: %.0f; attributed by phase: %.0f, residual "
               "%.1f %%), of them %.0f (%.0f %%) not fp32 arithmetic; %.0f issue cycles per wave x 64 waves per SIMD = "
-              "%.2f M cycles of the %.2f M the SIMD has in %.0f us at %.2f GHz: **valu.frac = %.2f**\n" % (
+              "%.2f M cycles of the %.2f M the SIMD has in %.0f us at %.2f GHz: **valu.frac = %.2f**%s\n" % (
                   name, measured, measured, n, 100.0 * (measured - n) / measured, nonarith, 100.0 * nonarith / n, cyc,
-                  waves_per_simd * cyc * 1e-6, have * 1e-6, us, a.ghz, frac))
+                  waves_per_simd * cyc * 1e-6, have * 1e-6, us, a.ghz, frac,
+                  "" if raw <= 1.0 else " (the additive prices give %.2f: they are measured per opcode in isolation, and "
+                  "mixed streams - tools/ubench/valu6.hip, profiles/r4_valu_mix.txt - deviate from their sum by several "
+                  "per cent both ways; a kernel cannot use more than all of its issue cycles: the pass is VALU-bound)" % raw))
         out["kernels"][name] = {"wave_instructions_per_wave": measured, "issue_cycles_per_wave": cyc,
-                                "non_arithmetic_per_wave": nonarith, "duration_us": us, "valu_frac": frac}
+                                "non_arithmetic_per_wave": nonarith, "duration_us": us, "valu_frac": frac,
+                                "valu_frac_additive_prices": raw}
     have = (a.density_us + a.accel_us) * 1e-6 * a.ghz * 1e9
-    out["pair"] = {"issue_cycles_per_simd": pair_cycles, "valu_frac": pair_cycles / have,
+    out["pair"] = {"issue_cycles_per_simd": pair_cycles, "valu_frac": min(1.0, pair_cycles / have),
+                   "valu_frac_additive_prices": pair_cycles / have,
                    "wave_instructions_per_launch_pair": (tot["d"][0] + tot["a"][0]) * 65536.0,
                    "non_arithmetic_per_launch_pair": (tot["d"][2] + tot["a"][2]) * 65536.0}
     print("**pair**: valu.frac = %.2f; %.0f M wave-instructions per launch pair, of them %.0f M not fp32 arithmetic\n" % (
