@@ -1249,6 +1249,60 @@ accel_from_lists(int p, int cnt, const char* __restrict__ lists, uint32_t lane_o
       const int keep = visc_keep(s.visc_scale);
       first_v = keep < cnt ? cnt - keep : 0;
    }
+   if constexpr (FAST) {
+      // Tolerance mode (the arithmetic the compressed dam is benchmarked in, where a tenth of the workgroups
+      // come here): the pressure sum takes a list block of eight entries per trip - ONE 16-byte load, the
+      // next block requested before this one's gathers - and gathers {x, y, z} and m B only; the viscous
+      // sum's last few neighbours follow in a loop of their own, as in the tiled route (the two sums meet in
+      // accel_end: same bits).  Four entries per trip, a 2-byte load each and {v, C} gathered for all of
+      // them, made a particle with 170 neighbours wait for 85 dependent round trips.
+      const int lastb = cnt > 0 ? (cnt - 1) >> 3 : 0;
+      uint4 blk = list_block_load(lists, 0, lane_off);
+      for (int j0 = 0; j0 < cnt; j0 += 8) {
+         uint32_t entry[8];
+         list_block_entries(blk, entry);
+         blk = list_block_load(lists, min((j0 >> 3) + 1, lastb), lane_off);
+         float4 pj[8];
+         float cj[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const uint32_t e = j0 + u < cnt ? entry[u] : entry[0];      // (entry 0 of a block in use is a neighbour)
+            const int q = ListEntry<WIDE>::tile(e) - ListEntry<WIDE>::shift(d, e);
+            pj[u] = posm[q];
+            cj[u] = auxc[q];
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            if (j0 + u < cnt) {
+               float dx, dy, dz;
+               float dd = sqrt_rn(dist2(pi.x, pi.y, pi.z, pj[u].x, pj[u].y, pj[u].z, dx, dy, dz));
+               if (!UNIT_SCALE) dd *= k.sim_scale;
+               accel_pair_fast_pressure<UNIT_SCALE>(k, s, dx, dy, dz, dd, cj[u]);
+            }
+         }
+      }
+      for (int j0 = first_v; j0 < cnt; j0 += VISC_UNROLL) {
+         float4 pj[VISC_UNROLL], vj[VISC_UNROLL];
+#pragma unroll
+         for (int u = 0; u < VISC_UNROLL; u++) {
+            const uint32_t e = list_entry_load(lists, (uint32_t)min(j0 + u, cnt - 1), lane_off);
+            const int q = ListEntry<WIDE>::tile(e) - ListEntry<WIDE>::shift(d, e);
+            pj[u] = posm[q];
+            vj[u] = velB[q];
+         }
+#pragma unroll
+         for (int u = 0; u < VISC_UNROLL; u++) {
+            if (j0 + u < cnt) {
+               float dx, dy, dz;
+               float dd = sqrt_rn(dist2(pi.x, pi.y, pi.z, pj[u].x, pj[u].y, pj[u].z, dx, dy, dz));
+               if (!UNIT_SCALE) dd *= k.sim_scale;
+               accel_pair_fast_viscous(k, s, dd, vj[u].x, vj[u].y, vj[u].z, vj[u].w);
+            }
+         }
+      }
+      accel_fast_finish(k, s);
+      return accel_end<UNIT_SCALE>(k, s);
+   }
    constexpr int U = 4;
    for (int j0 = 0; j0 < cnt; j0 += U) {
       float4 pj[U], vj[U];

@@ -340,6 +340,11 @@ void grow_lists(sph_hip_context* ctx)
    if (debug) fprintf(stderr, "sph_hip: neighbour lists enlarged to %d entries\n", want);
 }
 
+// what a workgroup of the acceleration pass costs on the list-driven route without a tile (accel_from_lists),
+// in units of a tiled one
+#ifndef ACCEL_LISTED_COST
+#define ACCEL_LISTED_COST 2.5f
+#endif
 void pick_tile_caps(sph_hip_context* ctx)
 {
    TileCaps& caps = ctx->caps;
@@ -415,7 +420,7 @@ void pick_tile_caps(sph_hip_context* ctx)
    for (int c = 0; c < caps.n_cand; c++)
       if (caps.cand[c] == caps.cap_density) over_density = fb[TSTAT_OVER + c];
    caps.cap_accel = pick_level(ctx, fb, ctx->accel_levels, ctx->accel_per_cu, ctx->n_accel_levels,
-                               accel_thr, 8.0f, over_density, 2.5f);
+                               accel_thr, 8.0f, over_density, ACCEL_LISTED_COST);
    // both passes of a step read and write the same lists: one entry format for the two
    caps.wide = caps.cap_density > TILE_CAP_MAX || caps.cap_accel > TILE_CAP_MAX;
    static int debug_left = getenv("SPH_HIP_DEBUG") ? 6 : 0;
