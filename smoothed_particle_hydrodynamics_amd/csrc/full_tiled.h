@@ -877,8 +877,8 @@ k_full_density_tiled(const float4* __restrict__ posm, const float4* __restrict__
 // has to search again the same way.  This kernel is launched BEFORE the tiled one when the last
 // step reported many of them, and stages the candidates through the same LDS tile in pieces:
 // segment after segment (ascending = canonical order), chunk after chunk of at most tile_cap
-// sorted positions.  Per chunk: TEST (the same screen) + append + SUM (confirming, four entries
-// per trip) as the tiled kernel does them.  List entries are the indices of the workgroup's
+// sorted positions.  Per chunk: TEST (the same screen), and every screened candidate confirmed, summed
+// and appended where it is popped (round 4; appends staged through LDS as in the tiled kernel).  List entries are the indices of the workgroup's
 // VIRTUAL tile (the layout its descriptor describes, wherever it would have been): the
 // acceleration pass - for which the tile is too large as well - walks them with operands from
 // global memory (accel_from_lists).  Same neighbours, same order, same arithmetic: same bits.
@@ -899,12 +899,18 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
 {
    __shared__ TileDesc sd;
    __shared__ int list_overflow;
+   // Chunks are a little shorter than the launch's capacity: what that leaves free behind the three arrays
+   // holds the append's staging slots (16 bytes per lane, as in the tiled kernel).  A capacity too small to
+   // spare them (pinned by a test) appends with 2-byte stores.
+   const int tid = threadIdx.x;
+   const bool staged = tile_cap >= 1024;
+   const int chunk_cap = staged ? tile_cap - 352 : tile_cap;      // (352 entries x 12 bytes >= 16 bytes x 256 lanes)
    TileLds L;
    L.x = tile_lds_dynamic;
-   L.y = L.x + (tile_cap + TILE_PAD);
-   L.z = L.y + (tile_cap + TILE_PAD);
+   L.y = L.x + (chunk_cap + TILE_PAD);
+   L.z = L.y + (chunk_cap + TILE_PAD);
+   char* const stage_lane = reinterpret_cast<char*>(L.z + (chunk_cap + TILE_PAD)) + 16 * tid;
    const int begin = meta[META_SUM_BEGIN], end = meta[META_SUM_END];
-   const int tid = threadIdx.x;
    const int n_giveup = tile_stats[TSTAT_GIVEUP_DENSITY];
    for (int gi = blockIdx.x; gi < n_giveup; gi += gridDim.x) {
       const int wg = (int)giveup[gi];
@@ -942,6 +948,7 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
       uint32_t pos = list_pos_of(0u);   // the append position (list_pos_of(entries this lane's list holds))
       int count = 0;
       float density = 0.0f;
+      if (staged) *reinterpret_cast<uint4*>(stage_lane) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
       for (int kk = 0; kk < 9; kk++) {
          const int off = ((kk / 3 - 1) * g.ny + (kk % 3 - 1)) * g.nx;
@@ -959,8 +966,8 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                       : kk == 5 ? r.s[5] : kk == 6 ? r.s[6] : kk == 7 ? r.s[7] : r.s[8];
          const int re = kk == 0 ? r.e[0] : kk == 1 ? r.e[1] : kk == 2 ? r.e[2] : kk == 3 ? r.e[3] : kk == 4 ? r.e[4]
                       : kk == 5 ? r.e[5] : kk == 6 ? r.e[6] : kk == 7 ? r.e[7] : r.e[8];
-         for (int c0 = G; c0 < G + len; c0 += tile_cap) {
-            const int have = min(tile_cap, G + len - c0);
+         for (int c0 = G; c0 < G + len; c0 += chunk_cap) {
+            const int have = min(chunk_cap, G + len - c0);
             __syncthreads();                 // the previous chunk's readers are done
             // (TILE_BATCH loads in flight before the first LDS store, as tile_load does: one load
             // waited for per trip made a chunk of 4 400 entries seventeen round trips long)
@@ -981,14 +988,13 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
             __syncthreads();
             // this lane's candidates inside the chunk, as chunk-local slots
             const int ts = max(rs - c0, 0), te = min(re - c0, have);
-            const int first_new = count;
             for (int t0 = (ts < te) ? (ts & ~3) : te; __any(t0 < te); t0 += 32) {
                uint32_t mask = 0;
-               if (t0 < te) {
+               if (t0 < te && count <= list_cap) {      // (a list that has overflowed stops here: the lane walks)
 #pragma unroll
                   for (int q8 = 0; q8 < 4; q8++) {
                      const int t = t0 + 8 * q8;
-                     // (the tiled kernel's screen: SUM below confirms on the reference's own value)
+                     // (the tiled kernel's screen: the pop below confirms on the reference's own value)
                      if (t < te) mask |= test8(L, t, px, py, pz, k.h2_screen) << (8 * q8);
                   }
                   const int lo_b = ts - t0, hi_b = te - t0;
@@ -998,66 +1004,54 @@ k_full_density_chunked(const float4* __restrict__ posm, const float4* __restrict
                      const int sb = (p - c0) - t0;      // the particle itself
                      if (sb >= 0 && sb < 32) mask &= ~(1u << sb);
                   }
-                  count += __builtin_popcount(mask);
-                  if (count > list_cap) {
-                     mask = 0u;
-                     count = list_cap + 1;
-                  }
                }
+               // Every screened candidate is confirmed where it is popped - the chunk is in LDS now, and
+               // only now: the reference's own test on the reference's own value, the density term, and
+               // the entry appended if (and only if) it counts.  (Until round 4 the entries were appended
+               // first and a second pass over the chunk's part of the list summed and compacted them:
+               // a 2-byte store and a 2-byte load per entry, and the lists read back from memory.  These
+               // workgroups are the heaviest of a compressed scene, where the vector ALUs idle and the
+               // memory path does not: the sum's arithmetic at the append's lane use is the cheaper side.)
                const uint32_t ebase = kbits | (uint32_t)(c0 + D + t0);
                while (__any(mask != 0u)) {
                   if (mask != 0u) {
                      const uint32_t bit = (uint32_t)__builtin_ctz(mask);
                      mask &= mask - 1u;
-                     *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
-                     pos = list_pos_next(pos);
-                  }
-               }
-            }
-            // SUM of what this chunk added, in list order (a lane reads what it has written: behind
-            // a barrier, as the tiled kernel's SUM is behind one).  TEST only screened: a pair that
-            // fails the reference's own test is left out of the sum and of the list, the entries
-            // behind it move up (the write position never passes the read position; a trip's
-            // words are in registers before its first store).
-            __syncthreads();
-            if (__any(count <= list_cap && first_new < count)) {
-               const int listed = count <= list_cap ? count : first_new;   // (an overflowed lane sums nothing)
-               int kept = first_new;
-               constexpr int CU = 4;
-               for (int j0 = first_new; __any(j0 < listed); j0 += CU) {
-                  uint32_t entry[CU];
-#pragma unroll
-                  for (int u = 0; u < CU; u++) {
-                     const int j = min(j0 + u, listed > first_new ? listed - 1 : first_new);
-                     entry[u] = list_entry_load(lists, (uint32_t)j, lane_off);
-                  }
-#pragma unroll
-                  for (int u = 0; u < CU; u++) {
-                     if (j0 + u < listed) {
-                        const int t = ListEntry<WIDE>::tile(entry[u]) - D - c0;
-                        float mj = pi.w;
-                        if (!UNIFORM_MASS) mj = posm[c0 + t].w;
-                        float dx, dy, dz;
-                        const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
-                        if (d2 < k.h2) {
-                           float d = sqrt_rn(d2);
-                           if (!UNIT_SCALE) d *= k.sim_scale;
-                           density_accumulate<UNIT_SCALE>(k, mj, d, density);
-                           if (kept != j0 + u)
-                              *reinterpret_cast<uint16_t*>(lists + list_entry_off((uint32_t)kept, lane_off)) = (uint16_t)entry[u];
-                           kept++;
+                     const int t = t0 + (int)bit;
+                     float mj = pi.w;
+                     if (!UNIFORM_MASS) mj = posm[c0 + t].w;
+                     float dx, dy, dz;
+                     const float d2 = dist2(pi.x, pi.y, pi.z, L.x[t], L.y[t], L.z[t], dx, dy, dz);
+                     if (d2 < k.h2) {
+                        float d = sqrt_rn(d2);
+                        if (!UNIT_SCALE) d *= k.sim_scale;
+                        density_accumulate<UNIT_SCALE>(k, mj, d, density);
+                        if (count >= list_cap) {        // one more than the list holds: no list for this particle
+                           count = list_cap + 1;
+                           mask = 0u;
+                        } else {
+                           count++;
+                           const uint32_t in_block = pos & 14u;
+                           if (staged) {
+                              *reinterpret_cast<uint16_t*>(stage_lane + in_block) = (uint16_t)(ebase + bit);
+                              if (in_block == 14u)
+                                 *reinterpret_cast<uint4*>(lists + list_pos_off(pos & ~14u, lane_off)) =
+                                    *reinterpret_cast<const uint4*>(stage_lane);
+                           } else {
+                              *reinterpret_cast<uint16_t*>(lists + list_pos_off(pos, lane_off)) = (uint16_t)(ebase + bit);
+                           }
+                           pos = list_pos_next(pos);
                         }
                      }
                   }
                }
-               if (count <= list_cap && kept != count) {     // the append position follows the list's end
-                  count = kept;
-                  pos = list_pos_of((uint32_t)count);
-               }
             }
          }
       }
-      list_pad(lists, lane_off, count, list_cap);
+      if (!staged)
+         list_pad(lists, lane_off, count, list_cap);
+      else if (count <= list_cap && ((count & 7) != 0 || count == 0))
+         *reinterpret_cast<uint4*>(lists + list_pos_off(pos & ~14u, lane_off)) = *reinterpret_cast<const uint4*>(stage_lane);
       const bool overflowed = count > list_cap;
       if (overflowed) {
          list_overflow = 1;
