@@ -342,6 +342,12 @@ void grow_lists(sph_hip_context* ctx)
 
 // what a workgroup of the acceleration pass costs on the list-driven route without a tile (accel_from_lists),
 // in units of a tiled one
+// ... and what a workgroup whose tile fits no capacity costs the density pass (k_full_density_chunked).
+// (Round 4: 3 since that kernel confirms at the pop and stages its appends; the 600-step transient of the
+// breaking 4M dam - tools/dam_windows.py - takes 1712 ms with 6, 1690 with 3, 1697 with 2, 1799 with 1.5.)
+#ifndef DENSITY_GIVEUP_COST
+#define DENSITY_GIVEUP_COST 3.0f
+#endif
 #ifndef ACCEL_LISTED_COST
 #define ACCEL_LISTED_COST 2.5f
 #endif
@@ -415,7 +421,7 @@ void pick_tile_caps(sph_hip_context* ctx)
    static const float density_thr[7] = {0.0f, 0.33f, 0.62f, 0.85f, 0.93f, 0.97f, 1.0f};
    static const float accel_thr[7] = {0.0f, 0.40f, 0.68f, 0.87f, 0.98f, 1.0f, 1.0f};
    caps.cap_density = pick_level(ctx, fb, ctx->density_levels, ctx->density_per_cu,
-                                 ctx->n_density_levels, density_thr, 6.0f);
+                                 ctx->n_density_levels, density_thr, DENSITY_GIVEUP_COST);
    int over_density = fb[TSTAT_BLOCKS];
    for (int c = 0; c < caps.n_cand; c++)
       if (caps.cand[c] == caps.cap_density) over_density = fb[TSTAT_OVER + c];
