@@ -1,3 +1,6 @@
+"""Which LDS tile capacities a build picks on the 4M column at rest and how many workgroups it leaves without
+a tile, plus the phase times of ten instrumented steps (SPH_HIP_LIBRARY selects the build): the quick check
+that a change to the kernels' LDS budget did not cost a capacity level (r4 notes 4c)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import smoothed_particle_hydrodynamics_amd as S
