@@ -80,6 +80,8 @@ __device__ __forceinline__ void integrate_particle(const PairConsts& k, float4& 
       agx = gm * (rsx / d3);
       agy = gm * (rsy / d3);
       agz = gm * (rsz / d3);
+   } else {
+      agx = agy = agz = (nx0 - nx0) + (ny0 - ny0) + (nz0 - nz0);   // 0, or NaN where the term is: see accel_end
    }
    if (k.apply_gravity) { // extension, as in accel_end
       agx += k.gx;

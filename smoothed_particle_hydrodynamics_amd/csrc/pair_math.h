@@ -281,6 +281,14 @@ __device__ __forceinline__ float4 accel_end(const PairConsts& k, const AccelStat
    ax += gm * (rsx / d3);
    ay += gm * (rsy / d3);
    az += gm * (rsz / d3);
+   } else {
+      // (... +-0 for a particle whose position is finite.  One that is not - a particle the reference has
+      // lost to a NaN two steps ago, seeded random scene 594 of the round-4 soak - gets NaN from the term,
+      // in all three components: x - x is 0 or NaN exactly when the term is.)
+      const float lost = (s.rx - s.rx) + (s.ry - s.ry) + (s.rz - s.rz);
+      ax += lost;
+      ay += lost;
+      az += lost;
    }
    if (k.apply_gravity) { // extension: uniform gravity enters next to the point-mass term
       ax += k.gx;

@@ -72,8 +72,10 @@ def test_random_scene(oracle, hiplib, case, mode):
 
 # cases the long soaks singled out (profiles/r3_notes.md, sections 7-8): 219 - one rim neighbour of next
 # to no density carries the whole force; 305 - velocities of 1e-6 and a force that cancels; 1751 - a
-# neighbour of density 3.5e-17: the reference's sum overflows and its clamp returns zeros
-SOAK_FINDS = [c for c in (219, 305, 1751) if c >= CASES]
+# neighbour of density 3.5e-17: the reference's sum overflows and its clamp returns zeros; 594 (round 4,
+# soak of 3000) - no point mass, and particles the reference lost to a NaN in the first step: the point-mass
+# term the tolerance mode skips is NaN for them in the second
+SOAK_FINDS = [c for c in (219, 305, 594, 1751) if c >= CASES]
 
 
 @pytest.mark.parametrize("case", list(range(CASES)) + SOAK_FINDS)
